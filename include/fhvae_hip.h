@@ -1,0 +1,239 @@
+/*
+ * fhvae_hip.h -- C ABI of libfhvae_hip.so: the MI355X (gfx950) hot path of the ScalableFHVAE
+ * training step.  The reference (BurnhamG/PyTorch-ScalableFHVAE) is pure Python on stock ATen
+ * CPU ops and has no FFI; every entry point below names the reference lines it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all buffers are caller-owned DEVICE memory, dense row-major
+ *     unless a leading dimension (ld*, in ELEMENTS) is given; kernels never allocate or free.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); no internal synchronisation, no global state, re-entrant -> graph-capturable.
+ *   - return value: 0 on success; FHVAE_ERR_* (<0) for argument errors detected on the host
+ *     before anything is launched; a positive hipError_t if a launch failed.
+ *   - dtype: FHVAE_F32 computes with exact-f32 MFMA (v_mfma_f32_16x16x4_f32) -- the parity mode;
+ *     FHVAE_BF16 uses bf16 MFMA operands with f32 accumulation and f32 cell state.
+ *   - "time-major" activations are (T, B, X): row index t*B + b.
+ */
+#ifndef FHVAE_HIP_H
+#define FHVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHVAE_ABI_VERSION 1
+
+enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
+
+enum {
+  FHVAE_OK = 0,
+  FHVAE_ERR_NULL = -1,   /* required pointer is NULL */
+  FHVAE_ERR_SHAPE = -2,  /* non-positive / inconsistent dimension */
+  FHVAE_ERR_DTYPE = -3,  /* unknown dtype code */
+  FHVAE_ERR_ALIGN = -4,  /* pointer / leading dimension not aligned as required */
+  FHVAE_ERR_LIMIT = -5   /* size beyond what the kernels index (int32 rows/cols) */
+};
+
+#define FHVAE_MAX_LAYERS 4
+
+int fhvae_abi_version(void);
+/* human-readable text for a return code (static storage) */
+const char* fhvae_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Linear layer:  y[M,N] = act(x[M,K] . w[N,K]^T + b[N])        (act = ReLU if relu != 0)
+ * replaces nn.Linear / VariableLinearLayer, simple_fhvae.py:127-134, :208-213.
+ * dtype selects the MFMA operand type of x and w; y (and b) are f32; y_lp (optional, may be
+ * NULL) receives a copy of y in the operand dtype (for chaining bf16 layers).
+ * ------------------------------------------------------------------------------------------ */
+int fhvae_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* b,
+                     float* y, int64_t ldy, void* y_lp, int64_t M, int64_t K, int64_t N, int relu,
+                     int dtype, void* stream);
+
+/* Backward of the above.  dy[M,N] f32 is the upstream gradient; if relu != 0, `y` (the forward
+ * OUTPUT) masks it (dy *= y > 0) and the masked gradient is written to `dy_masked` (M*N f32
+ * workspace, required iff relu).  Produces dx[M,K] f32 (may be NULL; += if dx_accumulate), and ACCUMULATES
+ * dw[N,K] += dy^T x, db[N] += colsum(dy) (either may be NULL).  x, w are f32 here (the weight
+ * gradient contraction runs on exact-f32 MFMA in both modes for round 1). */
+int fhvae_linear_bwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y,
+                     int64_t ldy, const float* dy, int64_t lddy, float* dy_masked, float* dx,
+                     int64_t lddx, float* dw, int64_t lddw, float* db, int64_t M, int64_t K,
+                     int64_t N, int relu, int dx_accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gaussian head + reparameterisation (K2):  mu = h.Wmu^T + bmu, logvar = h.Wlv^T + blv,
+ * sample = mu + eps * exp(0.5*logvar)   -- GaussianLayer.forward, simple_fhvae.py:211-216.
+ * eps is supplied by the caller (the reference draws it with randn_like, :215); eps == NULL
+ * skips the sample (decoder head: x_sample is computed and never used, simple_fhvae.py:102).
+ * h[M,K]; mu, logvar, sample, eps: [M,D] f32 dense.
+ * ------------------------------------------------------------------------------------------ */
+int fhvae_gauss_head_reparam_fwd(const void* h, int64_t ldh, const void* w_mu, const void* w_lv,
+                                 const float* b_mu, const float* b_lv, const float* eps, float* mu,
+                                 float* logvar, float* sample, int64_t M, int64_t K, int64_t D,
+                                 int dtype, void* stream);
+/* Elementwise part of the head's backward: given upstream d_mu, d_logvar, d_sample (any may be
+ * NULL = zero) produce the gradients w.r.t. the two linear outputs:
+ *   g_mu = d_mu + d_sample ; g_lv = d_logvar + d_sample * eps * 0.5 * exp(0.5*logvar)
+ * (the two linear layers' own backward is fhvae_linear_bwd). n = M*D elements. */
+int fhvae_gauss_reparam_bwd(const float* d_mu, const float* d_logvar, const float* d_sample,
+                            const float* eps, const float* logvar, float* g_mu, float* g_lv,
+                            int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-layer LSTM over a whole segment (K1), step-fused cells: one launch per wavefront step
+ * computes the 4-gate contraction on MFMA and applies sigmoid/tanh + the cell update in the
+ * epilogue.  There is NO reference body (fhvae.py:14 raises NotImplementedError); semantics are
+ * torch.nn.LSTM(batch_first) CPU: gate order i,f,g,o; gates = W_ih x + b_ih + W_hh h + b_hh.
+ * It stands where the FC pre-encoders/decoder stand in simple_fhvae.py:160-164,186-190,240-244.
+ *
+ * Layer-0 input at step t is [x_t (I cols) || xc (Ic cols)]: x is time-major (T,B,I) (may be
+ * NULL with I = 0), xc (B,Ic) is constant over time (may be NULL with Ic = 0); w_ih[0] is
+ * [4H, I+Ic].  Layers l >= 1 take h^{l-1}_t (H cols).  All layers share H.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fhvae_lstm_desc {
+  int32_t dtype;  /* FHVAE_F32 | FHVAE_BF16: type of x, xc, w_*, hs */
+  int32_t L;      /* layers, 1..FHVAE_MAX_LAYERS */
+  int64_t B, T, I, Ic, H;
+  const void* x;   /* (T,B,I) time-major, operand dtype */
+  const void* xc;  /* (B,Ic) operand dtype */
+  const void* w_ih[FHVAE_MAX_LAYERS]; /* [4H, I+Ic] (l=0) / [4H, H], operand dtype */
+  const void* w_hh[FHVAE_MAX_LAYERS]; /* [4H, H] */
+  const float* b_ih[FHVAE_MAX_LAYERS]; /* [4H] f32 */
+  const float* b_hh[FHVAE_MAX_LAYERS];
+  /* transposed weight copies, needed by the BF16 backward only (operand dtype):
+   * w_ih_t[l] = w_ih[l]^T ([H,4H], l >= 1), w_hh_t[l] = w_hh[l]^T ([H,4H]) */
+  const void* w_ih_t[FHVAE_MAX_LAYERS];
+  const void* w_hh_t[FHVAE_MAX_LAYERS];
+  /* forward outputs, saved for backward */
+  void* hs;      /* (L,T,B,H) operand dtype: h^l_t */
+  float* cs;     /* (L,T,B,H) f32: c^l_t */
+  float* gates;  /* (L,T,B,4H) f32: activated i,f,g,o (column blocks of H) */
+  float* hn;     /* (B, L*H) f32: final hidden state of every layer, concatenated (may be NULL) */
+  float* pre;    /* workspace (T,B,4H) f32 (I > 0) or (B,4H) (I == 0): layer-0 input projection */
+} fhvae_lstm_desc;
+
+int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream);
+
+typedef struct fhvae_lstm_bwd_desc {
+  fhvae_lstm_desc f;      /* the forward descriptor (same buffers, already filled by fwd) */
+  const float* d_hs_top;  /* (T,B,H) f32 gradient w.r.t. the top layer's h_t (may be NULL) */
+  const float* d_hn;      /* (B, L*H) f32 gradient w.r.t. hn (may be NULL) */
+  /* workspaces */
+  void* dgates;   /* (L,T,B,4H) operand dtype: gradient w.r.t. pre-activation gates */
+  float* dgsum;   /* (B,4H) f32: sum_t dgates of layer 0 (required iff Ic > 0) */
+  float* dc;      /* (L,B,H) f32: running cell-state gradient */
+  /* outputs (ACCUMULATED: += ; any may be NULL) */
+  float* dw_ih[FHVAE_MAX_LAYERS]; /* f32, same shapes as w_ih (master-gradient precision) */
+  float* dw_hh[FHVAE_MAX_LAYERS];
+  float* db_ih[FHVAE_MAX_LAYERS];
+  float* db_hh[FHVAE_MAX_LAYERS];
+  float* d_xc;    /* (B,Ic) f32, OVERWRITTEN (may be NULL) */
+  /* f32 copies of the layer inputs for the weight-gradient contraction (BF16 mode only; in F32
+   * mode they alias f.x / f.xc / f.hs): */
+  const float* x_f32;   /* (T,B,I) */
+  const float* xc_f32;  /* (B,Ic) */
+} fhvae_lstm_bwd_desc;
+
+int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * mu2 gather (K4): mu2[b,:] = table[idx[b],:]  -- torch.gather, simple_fhvae.py:53.
+ * bwd: dtable[idx[b],:] += dmu2[b,:] (float atomics; duplicate indices accumulate).
+ * idx is int64 (DataLoader collate, train_model.py:445); rows outside [0,S) -> error flag:
+ * the kernel writes zeros for them and sets *oob_flag (int32 device word, may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+int fhvae_mu2_gather_fwd(const float* table, const int64_t* idx, float* mu2, int64_t B, int64_t S,
+                         int64_t D, int32_t* oob_flag, void* stream);
+int fhvae_mu2_gather_bwd(const float* dmu2, const int64_t* idx, float* dtable, int64_t B, int64_t S,
+                         int64_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused variational lower bound (K3) -- simple_fhvae.py:105-116 with log_gauss :56-60, kld :62-69.
+ *   log_pmu2   = sum_d logN(mu2; 0, 1)
+ *   neg_kld_z2 = -sum_d KL(N(z2_mu, e^z2_lv) || N(mu2, 0.25))
+ *   neg_kld_z1 = -sum_d KL(N(z1_mu, e^z1_lv) || N(0, 1))
+ *   log_px_z   = sum_{t,f} logN(x; x_mu, e^x_lv)
+ *   lower_bound = log_px_z + neg_kld_z1 + neg_kld_z2 + log_pmu2 / num_segs
+ * x, x_mu, x_lv are addressed as base + b*sb + t*st + f (f contiguous) so that both the
+ * batch-major (B,T,F) layout of the reference and the time-major (T,B,F) layout of the LSTM
+ * decoder are read in place.  num_segs is int64 (B,) or NULL with nsegs_scalar used instead.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fhvae_elbo_desc {
+  int64_t B, T, F, D1, D2;
+  const float* x;    int64_t x_sb, x_st;
+  const float* x_mu; const float* x_lv; int64_t xo_sb, xo_st; /* shared strides of x_mu/x_lv */
+  const float* z1_mu; const float* z1_lv;  /* (B,D1) */
+  const float* z2_mu; const float* z2_lv;  /* (B,D2) */
+  const float* mu2;                        /* (B,D2) */
+  const int64_t* num_segs; double nsegs_scalar;
+  /* outputs (B,) f32 */
+  float* lower_bound; float* log_px_z; float* neg_kld_z1; float* neg_kld_z2; float* log_pmu2;
+} fhvae_elbo_desc;
+
+int fhvae_elbo_fwd(const fhvae_elbo_desc* d, void* stream);
+
+typedef struct fhvae_elbo_bwd_desc {
+  fhvae_elbo_desc f;
+  /* upstream gradients, (B,) f32, any may be NULL (= 0): */
+  const float* g_lower_bound; const float* g_log_px_z; const float* g_neg_kld_z1;
+  const float* g_neg_kld_z2; const float* g_log_pmu2;
+  int32_t reference_detach;  /* 1: no gradient into x_mu/x_lv and none from log_pmu2 into mu2
+                                (the .detach() calls at simple_fhvae.py:107,114) */
+  /* outputs, OVERWRITTEN; same layouts as the forward inputs; d_x_mu/d_x_lv may be NULL */
+  float* d_x_mu; float* d_x_lv;
+  float* d_z1_mu; float* d_z1_lv; float* d_z2_mu; float* d_z2_lv; float* d_mu2;
+} fhvae_elbo_bwd_desc;
+
+int fhvae_elbo_bwd(const fhvae_elbo_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Discriminative loss (K5): logits[b,s] = -sum_d (q[b,d]-table[s,d])^2 * inv_two_var,
+ * log-sum-exp over s, cross-entropy against idx  -- simple_fhvae.py:119-122 (the reference
+ * materialises (B,S,D) three times; here the table is streamed once per 256-query tile with an
+ * online max-subtracted log-sum-exp and nothing of size B*S is ever written).
+ *
+ * fwd writes per-query partials so that a row-sharded table can be combined across GPUs:
+ *   row_max[b], row_sumexp[b] over THIS table's rows, tgt_logit[b] = logit at row idx[b]-row0
+ *   (0 if that row is not in [row0, row0+S)); optionally lse[b] = row_max + log(row_sumexp) and, if
+ *   ce_mean != NULL, the single-shard scalar ce_mean = mean_b(lse - tgt_logit) (= the reference's
+ *   log_qy).
+ * ws: workspace of fhvae_disc_lse_ws_bytes(B,S) bytes.
+ * ------------------------------------------------------------------------------------------ */
+int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S);
+int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
+                       float inv_two_var, float* row_max, float* row_sumexp, float* tgt_logit,
+                       float* lse, float* ce_mean, void* ws, int64_t B, int64_t S, int64_t D,
+                       void* stream);
+/* bwd: given lse[b] (global log-sum-exp of query b over ALL shards) and the scalar scale
+ * g = (*g_scale) * g_mul  (= dL/d(ce_mean) / B_total), computes  p[b,s] = exp(logit - lse[b]),  w = g*(p - [s == idx[b]-row0])
+ *   dq[b,:]     = sum_s w * (-2 c)(q[b]-t[s])      OVERWRITTEN  (partial over this shard's rows)
+ *   dtable[s,:] += sum_b w * (+2 c)(q[b]-t[s])     ACCUMULATED
+ * g is read from device memory (g_scale, one f32) so the call stays graph-capturable. */
+int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
+                       float inv_two_var, const float* lse, const float* g_scale, float g_mul,
+                       float* dq, float* dtable, void* ws, int64_t B, int64_t S, int64_t D,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam (train_model.py:409-411: torch.optim.Adam(lr, betas=(beta_one, beta_two)), eps 1e-8, no
+ * weight decay) over one flat f32 buffer; step_count is read from device memory (int32, already
+ * incremented by this call) so a captured graph advances the bias correction.  p_lp (optional)
+ * receives the updated parameters in bf16.  grad_scale multiplies g first (1/world for DP).
+ * ------------------------------------------------------------------------------------------ */
+int fhvae_adam_step(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float grad_scale, int32_t* step_count,
+                    void* stream);
+
+/* small utilities used by the host side */
+/* (B,T,F) batch-major f32 -> (T,B,F) time-major in operand dtype `dtype` (and optionally f32) */
+int fhvae_to_time_major(const float* x_btf, void* x_tbf, float* x_tbf_f32, int64_t B, int64_t T,
+                        int64_t F, int dtype, void* stream);
+/* f32 -> bf16 cast, optional transposed copy: src [R,C] -> dst [R,C] and dst_t [C,R] (either NULL) */
+int fhvae_cast_bf16(const float* src, void* dst, void* dst_t, int64_t R, int64_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FHVAE_HIP_H */

@@ -1,0 +1,271 @@
+// gemm.hip -- generic linear-layer kernels on the shared MFMA engine (gemm_core.h):
+//   fhvae_linear_fwd / fhvae_linear_bwd / fhvae_gauss_head_reparam_fwd / fhvae_gauss_reparam_bwd.
+// Reference ops replaced: nn.Linear (+ReLU) at simple_fhvae.py:127-134 and the Gaussian layer at
+// simple_fhvae.py:193-216.
+#include "gemm_launch.h"
+
+namespace fh {
+
+// ---------------------------------------------------------------------------------------------
+// generic GEMM kernel: C = epi(sum_seg A.B^T)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
+  using TL = Tile<T, BM, BN, WM, WN>;
+  constexpr int TM = TL::TM, TN = TL::TN;
+  __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int nkb = num_kblocks<T>(p.seg);
+  // split-K: contiguous ranges of K-blocks per z-slice
+  const int per = (nkb + p.splitk - 1) / p.splitk;
+  const int it0 = blockIdx.z * per;
+  const int it1 = min(nkb, it0 + per);
+  if (it0 >= it1 && blockIdx.z > 0) return;
+
+  f32x4 acc[TM][TN];
+  zero_acc(acc);
+  RowIdent arm{p.M}, brm{p.N};
+  mainloop<T, BM, BN, WM, WN>(acc, p.seg, m0, p.M, n0, p.N, arm, brm, it0, it1, smem);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const bool first = blockIdx.z == 0;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + wn * (TN * 16) + tn * 16 + (lane & 15);
+      if (col >= p.N) continue;
+      float add = 0.f;
+      if (first) {
+        if (p.bias) add += p.bias[col];
+        if (p.bias2) add += p.bias2[col];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * (TM * 16) + tm * 16 + (lane >> 4) * 4 + r;
+        if (row >= p.M) continue;
+        float v = acc[tm][tn][r] + add;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.C) {
+          float* c = p.C + (int64_t)row * p.ldc + col;
+          if (p.mode == 0)
+            *c = v;
+          else if (p.mode == 1)
+            *c += v;
+          else
+            atomicAdd(c, v);
+        }
+        if (p.Clp) p.Clp[(int64_t)row * p.ldclp + col] = f2bf(v);
+      }
+    }
+}
+
+int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
+  GemmParams p = p_in;
+  if (p.M <= 0 || p.N <= 0) return FHVAE_ERR_SHAPE;
+  if (p.splitk < 1) p.splitk = 1;
+  dim3 grid((unsigned)fh_cdiv(p.N, 64), (unsigned)fh_cdiv(p.M, 64), (unsigned)p.splitk);
+  if (dtype == FHVAE_F32) {
+    hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 2, 2>), grid, dim3(kThreads), 0, st, p);
+  } else if (dtype == FHVAE_BF16) {
+    for (int s = 0; s < 2; ++s)
+      if (p.seg[s].K > 0 && (!p.seg[s].a_kc || !p.seg[s].b_kc)) return FHVAE_ERR_DTYPE;  // bf16: KC images only
+    hipLaunchKernelGGL((gemm_kernel<u16, 64, 64, 2, 2>), grid, dim3(kThreads), 0, st, p);
+  } else {
+    return FHVAE_ERR_DTYPE;
+  }
+  return fh_launch_status();
+}
+
+// heuristic split of the contraction for weight-gradient GEMMs (few output tiles, long K)
+int pick_splitk(int64_t M, int64_t N, int64_t K) {
+  int64_t tiles = fh_cdiv(M, 64) * fh_cdiv(N, 64);
+  int64_t nkb = fh_cdiv(K, 32);
+  if (tiles >= 256 || nkb < 16) return 1;
+  int64_t s = fh_cdiv(512, tiles);
+  if (s > nkb / 8) s = nkb / 8;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small elementwise / reduction helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void relu_mask_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
+                                 float* __restrict__ out, int64_t M, int64_t N) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  int64_t m = i / N, n = i % N;
+  out[i] = y[m * ldy + n] > 0.f ? dy[m * lddy + n] : 0.f;
+}
+
+// db[n] += sum_m g[m][n] : 64 columns x 4 row lanes per block, rows strided over gridDim.y
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int64_t ldg, float* __restrict__ db,
+                                                     float* __restrict__ db2, int64_t M, int64_t N) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (n < N)
+    for (int64_t m = (int64_t)blockIdx.y * 4 + rg; m < M; m += (int64_t)gridDim.y * 4) s += g[m * ldg + n];
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && n < N) {
+    float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (db) atomicAdd(db + n, t);
+    if (db2) atomicAdd(db2 + n, t);
+  }
+}
+
+int launch_colsum(const float* g, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st) {
+  if (!db && !db2) return FHVAE_OK;
+  int64_t gy = fh_cdiv(M, 4 * 16);
+  if (gy > 64) gy = 64;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)fh_cdiv(N, 64), (unsigned)gy), dim3(256), 0, st, g, ldg, db, db2, M, N);
+  return fh_launch_status();
+}
+
+__global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                   const float* __restrict__ eps, float* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = mu[i] + eps[i] * expf(0.5f * lv[i]);  // simple_fhvae.py:214-216
+}
+
+__global__ void reparam_bwd_kernel(const float* __restrict__ d_mu, const float* __restrict__ d_lv,
+                                   const float* __restrict__ d_s, const float* __restrict__ eps,
+                                   const float* __restrict__ lv, float* __restrict__ g_mu, float* __restrict__ g_lv,
+                                   int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float ds = d_s ? d_s[i] : 0.f;
+  g_mu[i] = (d_mu ? d_mu[i] : 0.f) + ds;
+  float e = (d_s && eps) ? ds * eps[i] * 0.5f * expf(0.5f * lv[i]) : 0.f;
+  g_lv[i] = (d_lv ? d_lv[i] : 0.f) + e;
+}
+
+}  // namespace fh
+
+using namespace fh;
+
+extern "C" int fhvae_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* b, float* y,
+                                int64_t ldy, void* y_lp, int64_t M, int64_t K, int64_t N, int relu, int dtype,
+                                void* stream) {
+  FH_CHECK_PTR(x);
+  FH_CHECK_PTR(w);
+  if (!y && !y_lp) return FHVAE_ERR_NULL;
+  FH_CHECK_POS(M);
+  FH_CHECK_POS(K);
+  FH_CHECK_POS(N);
+  FH_CHECK_I32(M);
+  FH_CHECK_I32(K);
+  FH_CHECK_I32(N);
+  if (ldx < K || ldw < K || (y && ldy < N)) return FHVAE_ERR_SHAPE;
+  GemmParams p = {};
+  p.seg[0] = Seg{x, ldx, 1, w, ldw, 1, (int)K};
+  p.M = (int)M;
+  p.N = (int)N;
+  p.C = y;
+  p.ldc = ldy;
+  p.Clp = (u16*)y_lp;
+  p.ldclp = N;
+  p.bias = b;
+  p.relu = relu;
+  p.splitk = 1;
+  return launch_gemm(p, dtype, (hipStream_t)stream);
+}
+
+extern "C" int fhvae_linear_bwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy,
+                                const float* dy, int64_t lddy, float* dy_masked, float* dx, int64_t lddx, float* dw,
+                                int64_t lddw, float* db, int64_t M, int64_t K, int64_t N, int relu, int dx_accumulate,
+                                void* stream) {
+  FH_CHECK_PTR(dy);
+  FH_CHECK_POS(M);
+  FH_CHECK_POS(K);
+  FH_CHECK_POS(N);
+  FH_CHECK_I32(M);
+  FH_CHECK_I32(K);
+  FH_CHECK_I32(N);
+  hipStream_t st = (hipStream_t)stream;
+  const float* g = dy;
+  int64_t ldg = lddy;
+  if (relu) {
+    FH_CHECK_PTR(y);
+    FH_CHECK_PTR(dy_masked);
+    int64_t n = M * N;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, dy, lddy, y, ldy, dy_masked, M, N);
+    int e = fh_launch_status();
+    if (e) return e;
+    g = dy_masked;
+    ldg = N;
+  }
+  if (dx) {
+    FH_CHECK_PTR(w);
+    // dx[M,K] = g[M,N] . w[N,K]: contraction over N; w is the KM operand B(k_out, n) = w[n*ldw + k_out]
+    GemmParams p = {};
+    p.seg[0] = Seg{g, ldg, 1, w, ldw, 0, (int)N};
+    p.M = (int)M;
+    p.N = (int)K;
+    p.C = dx;
+    p.ldc = lddx;
+    p.mode = dx_accumulate ? 1 : 0;
+    p.splitk = 1;
+    int e = launch_gemm(p, FHVAE_F32, st);
+    if (e) return e;
+  }
+  if (dw) {
+    FH_CHECK_PTR(x);
+    // dw[N,K] += g^T . x : contraction over M, both operands KM
+    GemmParams p = {};
+    p.seg[0] = Seg{g, ldg, 0, x, ldx, 0, (int)M};
+    p.M = (int)N;
+    p.N = (int)K;
+    p.C = dw;
+    p.ldc = lddw;
+    p.splitk = pick_splitk(N, K, M);
+    p.mode = p.splitk > 1 ? 2 : 1;
+    int e = launch_gemm(p, FHVAE_F32, st);
+    if (e) return e;
+  }
+  if (db) {
+    int e = launch_colsum(g, ldg, db, nullptr, M, N, st);
+    if (e) return e;
+  }
+  return FHVAE_OK;
+}
+
+extern "C" int fhvae_gauss_head_reparam_fwd(const void* h, int64_t ldh, const void* w_mu, const void* w_lv,
+                                            const float* b_mu, const float* b_lv, const float* eps, float* mu,
+                                            float* logvar, float* sample, int64_t M, int64_t K, int64_t D, int dtype,
+                                            void* stream) {
+  FH_CHECK_PTR(h);
+  FH_CHECK_PTR(w_mu);
+  FH_CHECK_PTR(w_lv);
+  FH_CHECK_PTR(mu);
+  FH_CHECK_PTR(logvar);
+  if (eps && !sample) return FHVAE_ERR_NULL;
+  int e = fhvae_linear_fwd(h, ldh, w_mu, K, b_mu, mu, D, nullptr, M, K, D, 0, dtype, stream);
+  if (e) return e;
+  e = fhvae_linear_fwd(h, ldh, w_lv, K, b_lv, logvar, D, nullptr, M, K, D, 0, dtype, stream);
+  if (e) return e;
+  if (eps) {
+    int64_t n = M * D;
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, mu, logvar,
+                       eps, sample, n);
+    return fh_launch_status();
+  }
+  return FHVAE_OK;
+}
+
+extern "C" int fhvae_gauss_reparam_bwd(const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
+                                       const float* logvar, float* g_mu, float* g_lv, int64_t n, void* stream) {
+  FH_CHECK_PTR(g_mu);
+  FH_CHECK_PTR(g_lv);
+  FH_CHECK_POS(n);
+  if (d_sample && (!eps || !logvar)) return FHVAE_ERR_NULL;
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, d_mu, d_logvar,
+                     d_sample, eps, logvar, g_mu, g_lv, n);
+  return fh_launch_status();
+}

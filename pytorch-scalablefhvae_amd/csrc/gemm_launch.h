@@ -1,0 +1,25 @@
+// gemm_launch.h -- host-side launcher of the generic GEMM kernel (gemm.hip), shared by lstm.hip.
+#pragma once
+#include "gemm_core.h"
+
+namespace fh {
+
+struct GemmParams {
+  Seg seg[2];
+  int M, N;
+  float* C;        // f32 output [M,N] (may be NULL if Clp given)
+  int64_t ldc;
+  u16* Clp;        // optional bf16 copy of the output
+  int64_t ldclp;
+  const float* bias;   // [N] added once (may be NULL)
+  const float* bias2;  // second [N] vector (b_ih + b_hh)
+  int relu;
+  int mode;    // 0: C = v   1: C += v   2: atomicAdd(C, v)  (required when splitk > 1)
+  int splitk;  // number of K slices (gridDim.z)
+};
+
+int launch_gemm(const GemmParams& p, int dtype, hipStream_t st);
+int pick_splitk(int64_t M, int64_t N, int64_t K);
+int launch_colsum(const float* g, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st);
+
+}  // namespace fh

@@ -1,0 +1,610 @@
+// loss.hip -- the HBM-streaming half of the hot path:
+//   K3 fused lower bound (simple_fhvae.py:105-116), K4 mu2 gather (:53), K5 discriminative
+//   log-sum-exp cross-entropy over the mu2 table (:119-122), fused Adam (train_model.py:409-411),
+//   layout utilities.
+#include "common.h"
+
+namespace fh {
+
+// prior constants of the reference (simple_fhvae.py:22-23, :88): float32(log 1) and float32(log 0.25)
+__device__ constexpr float kPz2Logvar = -1.3862943649291992f;  // np.log(0.5**2).astype(np.float32)
+__device__ constexpr float kLog2Pi = 1.8378770664093453f;
+
+// ---------------------------------------------------------------------------------------------
+// layout utilities
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void to_time_major_kernel(const float* __restrict__ x, T* __restrict__ o, float* __restrict__ of, int64_t B,
+                                     int64_t T_, int64_t F) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index into (T,B,F)
+  if (i >= B * T_ * F) return;
+  int64_t f = i % F, b = (i / F) % B, t = i / (F * B);
+  float v = x[(b * T_ + t) * F + f];
+  if constexpr (sizeof(T) == 4)
+    o[i] = v;
+  else
+    o[i] = f2bf(v);
+  if (of) of[i] = v;
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ s, u16* __restrict__ d, u16* __restrict__ dt, int64_t R,
+                                 int64_t C) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * C) return;
+  u16 v = f2bf(s[i]);
+  if (d) d[i] = v;
+  if (dt) dt[(i % C) * R + i / C] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 gather / scatter-add
+// ---------------------------------------------------------------------------------------------
+__global__ void gather_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                  float* __restrict__ out, int64_t B, int64_t S, int64_t D, int32_t* oob) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  int64_t b = i / D, d = i % D;
+  int64_t s = idx[b];
+  if (s < 0 || s >= S) {
+    out[i] = 0.f;
+    if (oob && d == 0) atomicOr(oob, 1);
+    return;
+  }
+  out[i] = table[s * D + d];
+}
+
+__global__ void gather_bwd_kernel(const float* __restrict__ dmu2, const int64_t* __restrict__ idx,
+                                  float* __restrict__ dtable, int64_t B, int64_t S, int64_t D) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  int64_t b = i / D, d = i % D;
+  int64_t s = idx[b];
+  if (s < 0 || s >= S) return;
+  atomicAdd(dtable + s * D + d, dmu2[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 fused lower bound: one wave per segment
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float nll_term(float x, float mu, float lv) {
+  const float df = x - mu;
+  return lv + df * df / expf(lv);  // log_gauss without the constant and the -0.5 (simple_fhvae.py:58-60)
+}
+
+__global__ __launch_bounds__(256) void elbo_fwd_kernel(fhvae_elbo_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= d.B) return;
+  const float* x = d.x + b * d.x_sb;
+  const float* xm = d.x_mu + b * d.xo_sb;
+  const float* xl = d.x_lv + b * d.xo_sb;
+  float s = 0.f;
+  const bool vec = (d.F % 4 == 0) && (d.x_sb % 4 == 0) && (d.x_st % 4 == 0) && (d.xo_sb % 4 == 0) &&
+                   (d.xo_st % 4 == 0) && ((((uintptr_t)d.x | (uintptr_t)d.x_mu | (uintptr_t)d.x_lv) & 15) == 0);
+  if (vec) {
+    const int F4 = (int)(d.F / 4);
+    const int n4 = (int)d.T * F4;
+    for (int i = lane; i < n4; i += 64) {
+      const int t = i / F4, f = (i % F4) * 4;
+      const float4 a = *(const float4*)(x + t * d.x_st + f);
+      const float4 m = *(const float4*)(xm + t * d.xo_st + f);
+      const float4 l = *(const float4*)(xl + t * d.xo_st + f);
+      s += nll_term(a.x, m.x, l.x) + nll_term(a.y, m.y, l.y) + nll_term(a.z, m.z, l.z) + nll_term(a.w, m.w, l.w);
+    }
+  } else {
+    const int n = (int)(d.T * d.F);
+    for (int i = lane; i < n; i += 64) {
+      const int t = i / (int)d.F, f = i % (int)d.F;
+      s += nll_term(x[t * d.x_st + f], xm[t * d.xo_st + f], xl[t * d.xo_st + f]);
+    }
+  }
+  s = wave_sum(s);
+  const float log_px_z = -0.5f * ((float)(d.T * d.F) * kLog2Pi + s);
+
+  // KL(q(z1|x) || N(0,1)) and KL(q(z2|x) || N(mu2, 0.25)), log N(mu2; 0, 1)   (simple_fhvae.py:62-69,106-112)
+  const float v2 = expf(kPz2Logvar);
+  float k1 = 0.f, k2 = 0.f, pm = 0.f;
+  for (int j = lane; j < d.D1; j += 64) {
+    const float mu = d.z1_mu[b * d.D1 + j], lv = d.z1_lv[b * d.D1 + j];
+    k1 += 1.f + lv - 0.f - (mu * mu + expf(lv)) / 1.f;
+  }
+  for (int j = lane; j < d.D2; j += 64) {
+    const float mu = d.z2_mu[b * d.D2 + j], lv = d.z2_lv[b * d.D2 + j], m2 = d.mu2[b * d.D2 + j];
+    const float df = mu - m2;
+    k2 += 1.f + lv - kPz2Logvar - (df * df + expf(lv)) / v2;
+    pm += kLog2Pi + m2 * m2;
+  }
+  k1 = 0.5f * wave_sum(k1);  // neg_kld = -sum(kld) = 0.5 * sum(...)
+  k2 = 0.5f * wave_sum(k2);
+  pm = -0.5f * wave_sum(pm);
+  if (lane == 0) {
+    const float ns = d.num_segs ? (float)d.num_segs[b] : (float)d.nsegs_scalar;
+    d.log_px_z[b] = log_px_z;
+    d.neg_kld_z1[b] = k1;
+    d.neg_kld_z2[b] = k2;
+    d.log_pmu2[b] = pm;
+    d.lower_bound[b] = log_px_z + k1 + k2 + pm / ns;
+  }
+}
+
+__global__ __launch_bounds__(256) void elbo_bwd_kernel(fhvae_elbo_bwd_desc bd) {
+  const fhvae_elbo_desc& d = bd.f;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= d.B) return;
+  const float glb = bd.g_lower_bound ? bd.g_lower_bound[b] : 0.f;
+  const float gpx = glb + (bd.g_log_px_z ? bd.g_log_px_z[b] : 0.f);
+  const float gk1 = glb + (bd.g_neg_kld_z1 ? bd.g_neg_kld_z1[b] : 0.f);
+  const float gk2 = glb + (bd.g_neg_kld_z2 ? bd.g_neg_kld_z2[b] : 0.f);
+  const float ns = d.num_segs ? (float)d.num_segs[b] : (float)d.nsegs_scalar;
+  const float gpm = glb / ns + (bd.g_log_pmu2 ? bd.g_log_pmu2[b] : 0.f);
+  if (bd.d_x_mu && bd.d_x_lv && !bd.reference_detach) {
+    const float* x = d.x + b * d.x_sb;
+    const float* xm = d.x_mu + b * d.xo_sb;
+    const float* xl = d.x_lv + b * d.xo_sb;
+    float* dm = bd.d_x_mu + b * d.xo_sb;
+    float* dl = bd.d_x_lv + b * d.xo_sb;
+    const int n = (int)(d.T * d.F);
+    for (int i = lane; i < n; i += 64) {
+      const int t = i / (int)d.F, f = i % (int)d.F;
+      const int64_t o = t * d.xo_st + f;
+      const float df = x[t * d.x_st + f] - xm[o];
+      const float iv = 1.f / expf(xl[o]);
+      dm[o] = gpx * df * iv;
+      dl[o] = gpx * -0.5f * (1.f - df * df * iv);
+    }
+  }
+  const float v2 = expf(kPz2Logvar);
+  for (int j = lane; j < d.D1; j += 64) {
+    const int64_t o = b * d.D1 + j;
+    const float mu = d.z1_mu[o], lv = d.z1_lv[o];
+    bd.d_z1_mu[o] = -mu * gk1;
+    bd.d_z1_lv[o] = 0.5f * (1.f - expf(lv)) * gk1;
+  }
+  for (int j = lane; j < d.D2; j += 64) {
+    const int64_t o = b * d.D2 + j;
+    const float mu = d.z2_mu[o], lv = d.z2_lv[o], m2 = d.mu2[o];
+    const float df = (mu - m2) / v2;
+    bd.d_z2_mu[o] = -df * gk2;
+    bd.d_z2_lv[o] = 0.5f * (1.f - expf(lv) / v2) * gk2;
+    bd.d_mu2[o] = df * gk2 + (bd.reference_detach ? 0.f : -m2 * gpm);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 discriminative log-sum-exp cross-entropy.
+// Forward: thread = query b (q row in registers), table rows are wave-uniform -> scalar loads
+// (s_load_dwordx*), so per (b,s) pair the VALU does only the 2*D sub/fma and the online-LSE
+// update; nothing of size B*S is written.  grid = (query tiles of 256) x (row chunks).
+// ---------------------------------------------------------------------------------------------
+struct DiscPlan {
+  int chunk;    // table rows per workgroup
+  int nchunks;
+  int btiles;
+};
+static inline DiscPlan disc_plan(int64_t B, int64_t S) {
+  DiscPlan p;
+  p.btiles = (int)fh_cdiv(B, 256);
+  int64_t want = fh_cdiv(1024, p.btiles);  // aim at ~1024 workgroups
+  int64_t chunk = fh_cdiv(S, want);
+  chunk = fh_cdiv(chunk, 8) * 8;
+  if (chunk < 8) chunk = 8;
+  p.chunk = (int)chunk;
+  p.nchunks = (int)fh_cdiv(S, chunk);
+  return p;
+}
+
+template <int D>
+__device__ __forceinline__ float sqdist(const float (&q)[D], const float* __restrict__ trow) {
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; d += 2) {
+    const float d0 = q[d] - trow[d], d1 = q[d + 1] - trow[d + 1];
+    a0 = fmaf(d0, d0, a0);
+    a1 = fmaf(d1, d1, a1);
+  }
+  return a0 + a1;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void disc_fwd_kernel(const float* __restrict__ q, const float* __restrict__ table,
+                                                       float c, float2* __restrict__ part, int B, int S, int chunk) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int bb = b < B ? b : B - 1;
+  float qr[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) qr[d] = q[(int64_t)bb * D + d];
+  const int s0 = blockIdx.y * chunk;
+  const int s1 = min(S, s0 + chunk);
+  float m = -INFINITY, sum = 0.f;
+  for (int s = s0; s < s1; s += 8) {
+    float l[8];
+    float gm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int su = s + u;
+      // rows past the chunk end are clamped (uniform scalar address) and masked to -inf
+      const float* trow = table + (int64_t)(su < s1 ? su : s1 - 1) * D;
+      l[u] = su < s1 ? -c * sqdist<D>(qr, trow) : -INFINITY;
+      gm = fmaxf(gm, l[u]);
+    }
+    if (gm > m) {
+      sum *= __expf(m - gm);  // m = -inf on the first group: exp(-inf) = 0
+      m = gm;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += __expf(l[u] - m);
+  }
+  if (b < B) part[(int64_t)blockIdx.y * B + b] = make_float2(m, sum);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void disc_combine_kernel(const float* __restrict__ q, const float* __restrict__ table,
+                                                           const int64_t* __restrict__ idx, int64_t row0, float c,
+                                                           const float2* __restrict__ part, int nchunks,
+                                                           float* __restrict__ row_max, float* __restrict__ row_sum,
+                                                           float* __restrict__ tgt, float* __restrict__ lse, int B,
+                                                           int S) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float m = -INFINITY, sum = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    const float2 p = part[(int64_t)k * B + b];
+    if (p.x > m) {
+      sum = sum * __expf(m - p.x) + p.y;
+      m = p.x;
+    } else {
+      sum += p.y * __expf(p.x - m);
+    }
+  }
+  row_max[b] = m;
+  row_sum[b] = sum;
+  if (lse) lse[b] = m + logf(sum);
+  const int64_t s = idx[b] - row0;
+  float t = 0.f;
+  if (s >= 0 && s < S) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float df = q[(int64_t)b * D + d] - table[s * D + d];
+      a = fmaf(df, df, a);
+    }
+    t = -c * a;
+  }
+  tgt[b] = t;
+}
+
+// single-workgroup deterministic mean of (max + log(sumexp) - target)
+__global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ row_max, const float* __restrict__ row_sum,
+                                                      const float* __restrict__ tgt, float* __restrict__ out, int B) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) s += row_max[b] + logf(row_sum[b]) - tgt[b];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
+// Backward, query side: dq[b,:] = -2c * sum_s w_bs (q_b - t_s), w = g (p - onehot)
+template <int D>
+__global__ __launch_bounds__(256) void disc_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ table,
+                                                          const int64_t* __restrict__ idx, int64_t row0, float c,
+                                                          const float* __restrict__ lse, const float* __restrict__ gsc,
+                                                          float gmul, float* __restrict__ dq, int B, int S, int chunk) {
+  __shared__ float tr[256][D + 1];
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int bb = b < B ? b : B - 1;
+  float qr[D], V[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    qr[d] = q[(int64_t)bb * D + d];
+    V[d] = 0.f;
+  }
+  const float g = *gsc * gmul;
+  const float ls = lse[bb];
+  const int64_t tg = idx[bb] - row0;
+  float W = 0.f;
+  const int s0 = blockIdx.y * chunk, s1 = min(S, s0 + chunk);
+  for (int s = s0; s < s1; ++s) {
+    const float* trow = table + (int64_t)s * D;
+    const float lg = -c * sqdist<D>(qr, trow);
+    float w = g * (__expf(lg - ls) - (s == tg ? 1.f : 0.f));
+    W += w;
+#pragma unroll
+    for (int d = 0; d < D; ++d) V[d] = fmaf(w, trow[d], V[d]);
+  }
+  // transpose through LDS so the atomics go out as contiguous rows (MI355X_MICROARCH.md, float atomics)
+#pragma unroll
+  for (int d = 0; d < D; ++d) tr[threadIdx.x][d] = -2.f * c * (qr[d] * W - V[d]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256 * D; i += 256) {
+    const int r = i / D, d = i % D;
+    const int br = blockIdx.x * 256 + r;
+    if (br < B) atomicAdd(dq + (int64_t)br * D + d, tr[r][d]);
+  }
+}
+
+// Backward, table side: thread = table row s (row in registers), queries are wave-uniform.
+// dtable[s,:] += 2c * sum_b w_bs (q_b - t_s)
+template <int D>
+__global__ __launch_bounds__(256) void disc_bwd_dt_kernel(const float* __restrict__ q, const float* __restrict__ table,
+                                                          const int64_t* __restrict__ idx, int64_t row0, float c,
+                                                          const float* __restrict__ lse, const float* __restrict__ gsc,
+                                                          float gmul, float* __restrict__ dtable, int B, int S, int bchunk) {
+  __shared__ float tr[256][D + 1];
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int ss = s < S ? s : S - 1;
+  float t[D], U[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    t[d] = table[(int64_t)ss * D + d];
+    U[d] = 0.f;
+  }
+  const float g = *gsc * gmul;
+  float W = 0.f;
+  const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+  for (int b = b0; b < b1; ++b) {
+    const float* qrow = q + (int64_t)b * D;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; d += 2) {
+      const float d0 = qrow[d] - t[d], d1 = qrow[d + 1] - t[d + 1];
+      a0 = fmaf(d0, d0, a0);
+      a1 = fmaf(d1, d1, a1);
+    }
+    const float lg = -c * (a0 + a1);
+    const float w = g * (__expf(lg - lse[b]) - ((int64_t)s == idx[b] - row0 ? 1.f : 0.f));
+    W += w;
+#pragma unroll
+    for (int d = 0; d < D; ++d) U[d] = fmaf(w, qrow[d], U[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) tr[threadIdx.x][d] = 2.f * c * (U[d] - t[d] * W);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256 * D; i += 256) {
+    const int r = i / D, d = i % D;
+    const int sr = blockIdx.x * 256 + r;
+    if (sr < S) atomicAdd(dtable + (int64_t)sr * D + d, tr[r][d]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, u16* __restrict__ plp, int64_t n, float lr, float b1, float b2,
+                            float eps, float gscale, const int32_t* __restrict__ step) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float t = (float)(*step);
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float gi = g[i] * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  const float pi = p[i] - (lr / bc1) * (mi / denom);
+  p[i] = pi;
+  if (plp) plp[i] = f2bf(pi);
+}
+
+}  // namespace fh
+
+using namespace fh;
+
+extern "C" int fhvae_abi_version(void) { return FHVAE_ABI_VERSION; }
+
+extern "C" const char* fhvae_strerror(int code) {
+  switch (code) {
+    case FHVAE_OK: return "ok";
+    case FHVAE_ERR_NULL: return "required pointer is NULL";
+    case FHVAE_ERR_SHAPE: return "bad or inconsistent dimension";
+    case FHVAE_ERR_DTYPE: return "unsupported dtype for this entry point";
+    case FHVAE_ERR_ALIGN: return "pointer or leading dimension not aligned";
+    case FHVAE_ERR_LIMIT: return "dimension exceeds kernel index range";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+extern "C" int fhvae_to_time_major(const float* x_btf, void* x_tbf, float* x_tbf_f32, int64_t B, int64_t T, int64_t F,
+                                   int dtype, void* stream) {
+  FH_CHECK_PTR(x_btf);
+  FH_CHECK_PTR(x_tbf);
+  FH_CHECK_POS(B);
+  FH_CHECK_POS(T);
+  FH_CHECK_POS(F);
+  const int64_t n = B * T * F;
+  dim3 grid((unsigned)fh_cdiv(n, 256));
+  if (dtype == FHVAE_F32)
+    hipLaunchKernelGGL((to_time_major_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x_btf, (float*)x_tbf,
+                       x_tbf_f32, B, T, F);
+  else if (dtype == FHVAE_BF16)
+    hipLaunchKernelGGL((to_time_major_kernel<u16>), grid, dim3(256), 0, (hipStream_t)stream, x_btf, (u16*)x_tbf, x_tbf_f32,
+                       B, T, F);
+  else
+    return FHVAE_ERR_DTYPE;
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_cast_bf16(const float* src, void* dst, void* dst_t, int64_t R, int64_t C, void* stream) {
+  FH_CHECK_PTR(src);
+  if (!dst && !dst_t) return FHVAE_ERR_NULL;
+  FH_CHECK_POS(R);
+  FH_CHECK_POS(C);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)fh_cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (u16*)dst, (u16*)dst_t, R, C);
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_mu2_gather_fwd(const float* table, const int64_t* idx, float* mu2, int64_t B, int64_t S, int64_t D,
+                                    int32_t* oob_flag, void* stream) {
+  FH_CHECK_PTR(table);
+  FH_CHECK_PTR(idx);
+  FH_CHECK_PTR(mu2);
+  FH_CHECK_POS(B);
+  FH_CHECK_POS(S);
+  FH_CHECK_POS(D);
+  hipLaunchKernelGGL(gather_fwd_kernel, dim3((unsigned)fh_cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, table, idx,
+                     mu2, B, S, D, oob_flag);
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_mu2_gather_bwd(const float* dmu2, const int64_t* idx, float* dtable, int64_t B, int64_t S, int64_t D,
+                                    void* stream) {
+  FH_CHECK_PTR(dmu2);
+  FH_CHECK_PTR(idx);
+  FH_CHECK_PTR(dtable);
+  FH_CHECK_POS(B);
+  FH_CHECK_POS(S);
+  FH_CHECK_POS(D);
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)fh_cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, dmu2, idx,
+                     dtable, B, S, D);
+  return fh_launch_status();
+}
+
+static int check_elbo(const fhvae_elbo_desc* d) {
+  FH_CHECK_PTR(d);
+  FH_CHECK_POS(d->B);
+  FH_CHECK_POS(d->T);
+  FH_CHECK_POS(d->F);
+  FH_CHECK_POS(d->D1);
+  FH_CHECK_POS(d->D2);
+  FH_CHECK_I32(d->T * d->F);
+  FH_CHECK_PTR(d->x);
+  FH_CHECK_PTR(d->x_mu);
+  FH_CHECK_PTR(d->x_lv);
+  FH_CHECK_PTR(d->z1_mu);
+  FH_CHECK_PTR(d->z1_lv);
+  FH_CHECK_PTR(d->z2_mu);
+  FH_CHECK_PTR(d->z2_lv);
+  FH_CHECK_PTR(d->mu2);
+  if (!d->num_segs && !(d->nsegs_scalar > 0)) return FHVAE_ERR_SHAPE;
+  return FHVAE_OK;
+}
+
+extern "C" int fhvae_elbo_fwd(const fhvae_elbo_desc* d, void* stream) {
+  int e = check_elbo(d);
+  if (e) return e;
+  FH_CHECK_PTR(d->lower_bound);
+  FH_CHECK_PTR(d->log_px_z);
+  FH_CHECK_PTR(d->neg_kld_z1);
+  FH_CHECK_PTR(d->neg_kld_z2);
+  FH_CHECK_PTR(d->log_pmu2);
+  hipLaunchKernelGGL(elbo_fwd_kernel, dim3((unsigned)fh_cdiv(d->B, 4)), dim3(256), 0, (hipStream_t)stream, *d);
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_elbo_bwd(const fhvae_elbo_bwd_desc* d, void* stream) {
+  FH_CHECK_PTR(d);
+  int e = check_elbo(&d->f);
+  if (e) return e;
+  FH_CHECK_PTR(d->d_z1_mu);
+  FH_CHECK_PTR(d->d_z1_lv);
+  FH_CHECK_PTR(d->d_z2_mu);
+  FH_CHECK_PTR(d->d_z2_lv);
+  FH_CHECK_PTR(d->d_mu2);
+  if (!d->reference_detach && (!d->d_x_mu || !d->d_x_lv)) return FHVAE_ERR_NULL;
+  hipLaunchKernelGGL(elbo_bwd_kernel, dim3((unsigned)fh_cdiv(d->f.B, 4)), dim3(256), 0, (hipStream_t)stream, *d);
+  return fh_launch_status();
+}
+
+extern "C" int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S) {
+  if (B <= 0 || S <= 0) return 0;
+  DiscPlan p = disc_plan(B, S);
+  return (int64_t)p.nchunks * B * (int64_t)sizeof(float2);
+}
+
+#define DISC_DISPATCH(D_, CALL) \
+  switch (D_) {                 \
+    case 4: { constexpr int DD = 4; CALL; } break;   \
+    case 8: { constexpr int DD = 8; CALL; } break;   \
+    case 16: { constexpr int DD = 16; CALL; } break; \
+    case 32: { constexpr int DD = 32; CALL; } break; \
+    case 64: { constexpr int DD = 64; CALL; } break; \
+    default: return FHVAE_ERR_SHAPE;                 \
+  }
+
+extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float inv_two_var,
+                                  float* row_max, float* row_sumexp, float* tgt_logit, float* lse, float* ce_mean, void* ws,
+                                  int64_t B, int64_t S, int64_t D, void* stream) {
+  FH_CHECK_PTR(q);
+  FH_CHECK_PTR(table);
+  FH_CHECK_PTR(idx);
+  FH_CHECK_PTR(row_max);
+  FH_CHECK_PTR(row_sumexp);
+  FH_CHECK_PTR(tgt_logit);
+  FH_CHECK_PTR(ws);
+  FH_CHECK_POS(B);
+  FH_CHECK_POS(S);
+  FH_CHECK_I32(B);
+  FH_CHECK_I32(S);
+  hipStream_t st = (hipStream_t)stream;
+  DiscPlan p = disc_plan(B, S);
+  float2* part = (float2*)ws;
+  dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
+  DISC_DISPATCH(D, hipLaunchKernelGGL((disc_fwd_kernel<DD>), grid, dim3(256), 0, st, q, table, inv_two_var, part, (int)B,
+                                      (int)S, p.chunk));
+  int e = fh_launch_status();
+  if (e) return e;
+  DISC_DISPATCH(D, hipLaunchKernelGGL((disc_combine_kernel<DD>), dim3((unsigned)p.btiles), dim3(256), 0, st, q, table, idx,
+                                      row0, inv_two_var, part, p.nchunks, row_max, row_sumexp, tgt_logit, lse, (int)B,
+                                      (int)S));
+  e = fh_launch_status();
+  if (e) return e;
+  if (ce_mean) {
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, row_max, row_sumexp, tgt_logit, ce_mean, (int)B);
+    e = fh_launch_status();
+  }
+  return e;
+}
+
+extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float inv_two_var,
+                                  const float* lse, const float* g_scale, float g_mul, float* dq, float* dtable, void* ws,
+                                  int64_t B, int64_t S, int64_t D, void* stream) {
+  FH_CHECK_PTR(q);
+  FH_CHECK_PTR(table);
+  FH_CHECK_PTR(idx);
+  FH_CHECK_PTR(lse);
+  FH_CHECK_PTR(g_scale);
+  FH_CHECK_POS(B);
+  FH_CHECK_POS(S);
+  FH_CHECK_I32(B);
+  FH_CHECK_I32(S);
+  (void)ws;
+  hipStream_t st = (hipStream_t)stream;
+  if (dq) {
+    hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
+    if (he != hipSuccess) return (int)he;
+    DiscPlan p = disc_plan(B, S);
+    dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
+    DISC_DISPATCH(D, hipLaunchKernelGGL((disc_bwd_dq_kernel<DD>), grid, dim3(256), 0, st, q, table, idx, row0, inv_two_var,
+                                        lse, g_scale, g_mul, dq, (int)B, (int)S, p.chunk));
+    int e = fh_launch_status();
+    if (e) return e;
+  }
+  if (dtable) {
+    DiscPlan p = disc_plan(S, B);  // roles swapped: threads = rows, chunks over queries
+    dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
+    DISC_DISPATCH(D, hipLaunchKernelGGL((disc_bwd_dt_kernel<DD>), grid, dim3(256), 0, st, q, table, idx, row0, inv_two_var,
+                                        lse, g_scale, g_mul, dtable, (int)B, (int)S, p.chunk));
+    int e = fh_launch_status();
+    if (e) return e;
+  }
+  return FHVAE_OK;
+}
+
+extern "C" int fhvae_adam_step(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
+                               float beta2, float eps, float grad_scale, int32_t* step_count, void* stream) {
+  FH_CHECK_PTR(p);
+  FH_CHECK_PTR(g);
+  FH_CHECK_PTR(m);
+  FH_CHECK_PTR(v);
+  FH_CHECK_PTR(step_count);
+  FH_CHECK_POS(n);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (u16*)p_lp, n, lr, beta1, beta2, eps, grad_scale, step_count);
+  return fh_launch_status();
+}

@@ -1,0 +1,421 @@
+// lstm.hip -- K1: multi-layer LSTM over a whole segment with step-fused cells.
+//
+// No reference body exists (fhvae.py:14 raises NotImplementedError); semantics = torch.nn.LSTM CPU
+// (gate order i,f,g,o).  These kernels stand where the FC pre-encoders / pre-decoder stand in
+// simple_fhvae.py:160-164, :186-190, :240-244.
+//
+// Schedule (see DESIGN.md "K1"): the recurrence needs every hidden unit of step t-1 before step t,
+// i.e. an all-to-all between workgroups per step.  On gfx950 a dependent kernel boundary (~1.5 us)
+// is cheaper than any in-launch grid barrier (4-7 us, MI355X_MICROARCH.md price list), so each
+// WAVEFRONT step (layer l at time t together with layer l-1 at time t+1) is one launch of
+// (B/64) x (H/16) x jobs workgroups, and the whole sequence is meant to be replayed from a hipGraph.
+// Inside a launch one workgroup computes the four gate pre-activations of 64 segments x 16 hidden
+// units on MFMA (virtual column order: gate-major inside the tile, so one lane owns i,f,g,o of the
+// same (segment, unit)) and applies sigmoid/tanh + the cell update in registers: the (B,4H)
+// pre-activations never touch HBM.
+#include "gemm_launch.h"
+
+namespace fh {
+
+// ---------------------------------------------------------------------------------------------
+// forward cell
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct FwdJob {
+  Seg seg[2];           // seg0: layer input x W_ih (l >= 1), seg1: h_{t-1} x W_hh (t >= 1); K = 0 when absent
+  const float* pre;     // [B,4H] additive term incl. biases (l == 0) or NULL
+  int64_t pre_ld;
+  const float* bias_a;  // [4H] (l >= 1) or NULL
+  const float* bias_b;
+  const float* c_prev;  // [B,H] or NULL (t == 0)
+  float* c_out;         // [B,H]
+  T* h_out;             // [B,H] operand dtype
+  float* gates_out;     // [B,4H] activated i,f,g,o
+  float* hn_out;        // optional slot in the (B, L*H) final-state buffer (t == T-1)
+  int64_t hn_ld;
+};
+template <typename T>
+struct FwdJobs {
+  int B, H;
+  FwdJob<T> job[FHVAE_MAX_LAYERS];
+};
+
+// virtual column n of the gate matrix -> physical weight row: tiles of 64 = 4 gates x 16 units
+struct GateRowMap {
+  int H;
+  __device__ __forceinline__ int64_t operator()(int n) const {
+    int unit = (n >> 6) * 16 + (n & 15);
+    int gate = (n & 63) >> 4;
+    return unit < H ? (int64_t)gate * H + unit : -1;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void store_h(T* p, float v);
+template <>
+__device__ __forceinline__ void store_h<float>(float* p, float v) {
+  *p = v;
+}
+template <>
+__device__ __forceinline__ void store_h<u16>(u16* p, float v) {
+  *p = f2bf(v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs) {
+  constexpr int BM = 64, BN = 64, WM = 4, WN = 1;
+  using TL = Tile<T, BM, BN, WM, WN>;
+  __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
+  const FwdJob<T>& J = jobs.job[blockIdx.z];
+  const int B = jobs.B, H = jobs.H;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  f32x4 acc[1][4];
+  zero_acc(acc);
+  RowIdent arm{B};
+  GateRowMap brm{H};
+  const int nkb = num_kblocks<T>(J.seg);
+  mainloop<T, BM, BN, WM, WN>(acc, J.seg, m0, B, n0, (int)gridDim.x * 64, arm, brm, 0, nkb, smem);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 16 + (lane & 15);
+  if (unit >= H) return;
+  float badd[4] = {0.f, 0.f, 0.f, 0.f};
+  if (J.bias_a) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) badd[g] = J.bias_a[g * H + unit] + J.bias_b[g * H + unit];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + wave * 16 + (lane >> 4) * 4 + r;
+    if (row >= B) continue;
+    float pa[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      pa[g] = acc[0][g][r] + badd[g];
+      if (J.pre) pa[g] += J.pre[(int64_t)row * J.pre_ld + g * H + unit];
+    }
+    const float ig = sigmoidf_(pa[0]), fg = sigmoidf_(pa[1]), gg = tanhf(pa[2]), og = sigmoidf_(pa[3]);
+    const float cp = J.c_prev ? J.c_prev[(int64_t)row * H + unit] : 0.f;
+    const float c = fg * cp + ig * gg;
+    const float h = og * tanhf(c);
+    J.c_out[(int64_t)row * H + unit] = c;
+    store_h<T>(J.h_out + (int64_t)row * H + unit, h);
+    float* go = J.gates_out + (int64_t)row * 4 * H + unit;
+    go[0] = ig;
+    go[H] = fg;
+    go[2 * H] = gg;
+    go[3 * H] = og;
+    if (J.hn_out) J.hn_out[(int64_t)row * J.hn_ld + unit] = h;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward cell: dh_t = dg^l_{t+1} . W_hh[l] + dg^{l+1}_t . W_ih[l+1] (+ external), then the
+// elementwise LSTM backward in the epilogue -> dg^l_t (pre-activation gate gradients)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct BwdJob {
+  Seg seg[2];
+  const float* ext;   // [B,H] external dh (top layer: d_hs_top[t]) or NULL
+  int64_t ext_ld;
+  const float* ext2;  // [B,H] slot of d_hn (t == T-1) or NULL
+  int64_t ext2_ld;
+  const float* gates;   // [B,4H] saved activations
+  const float* c_prev;  // [B,H] or NULL
+  const float* c_cur;   // [B,H]
+  float* dc;            // [B,H] running dL/dc (already multiplied by f of the later step)
+  int first;            // 1 at t == T-1: dc input is zero
+  T* dg_out;            // [B,4H]
+  float* dg_out_f32;    // optional f32 copy (bf16 mode: operands of the f32 weight-gradient GEMMs)
+  float* dgsum;         // optional [B,4H] running sum over t (layer 0 with a time-constant input)
+};
+template <typename T>
+struct BwdJobs {
+  int B, H;
+  BwdJob<T> job[FHVAE_MAX_LAYERS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs) {
+  constexpr int BM = 32, BN = 32, WM = 2, WN = 2;
+  using TL = Tile<T, BM, BN, WM, WN>;
+  __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
+  const BwdJob<T>& J = jobs.job[blockIdx.z];
+  const int B = jobs.B, H = jobs.H;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  f32x4 acc[1][1];
+  zero_acc(acc);
+  RowIdent arm{B}, brm{H};
+  const int nkb = num_kblocks<T>(J.seg);
+  mainloop<T, BM, BN, WM, WN>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int unit = n0 + wn * 16 + (lane & 15);
+  if (unit >= H) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + wm * 16 + (lane >> 4) * 4 + r;
+    if (row >= B) continue;
+    float dh = acc[0][0][r];
+    if (J.ext) dh += J.ext[(int64_t)row * J.ext_ld + unit];
+    if (J.ext2) dh += J.ext2[(int64_t)row * J.ext2_ld + unit];
+    const float* gp = J.gates + (int64_t)row * 4 * H + unit;
+    const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+    const int64_t o = (int64_t)row * H + unit;
+    const float cp = J.c_prev ? J.c_prev[o] : 0.f;
+    const float tc = tanhf(J.c_cur[o]);
+    float dc = dh * og * (1.f - tc * tc);
+    if (!J.first) dc += J.dc[o];
+    const float d_o = dh * tc;
+    const float d_i = dc * gg, d_f = dc * cp, d_g = dc * ig;
+    J.dc[o] = dc * fg;
+    float dp[4];
+    dp[0] = d_i * ig * (1.f - ig);
+    dp[1] = d_f * fg * (1.f - fg);
+    dp[2] = d_g * (1.f - gg * gg);
+    dp[3] = d_o * og * (1.f - og);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t go = (int64_t)row * 4 * H + g * H + unit;
+      store_h<T>(J.dg_out + go, dp[g]);
+      if (J.dg_out_f32) J.dg_out_f32[go] = dp[g];
+      if (J.dgsum) J.dgsum[go] = J.first ? dp[g] : J.dgsum[go] + dp[g];
+    }
+  }
+}
+
+}  // namespace fh
+
+using namespace fh;
+
+static int check_desc(const fhvae_lstm_desc* d) {
+  FH_CHECK_PTR(d);
+  if (d->dtype != FHVAE_F32 && d->dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
+  if (d->L < 1 || d->L > FHVAE_MAX_LAYERS) return FHVAE_ERR_SHAPE;
+  FH_CHECK_POS(d->B);
+  FH_CHECK_POS(d->T);
+  FH_CHECK_POS(d->H);
+  if (d->I < 0 || d->Ic < 0 || d->I + d->Ic <= 0) return FHVAE_ERR_SHAPE;
+  FH_CHECK_I32(d->B * d->T);
+  FH_CHECK_I32(4 * d->H);
+  FH_CHECK_I32(d->I + d->Ic);
+  if (d->I > 0) FH_CHECK_PTR(d->x);
+  if (d->Ic > 0) FH_CHECK_PTR(d->xc);
+  for (int l = 0; l < d->L; ++l) {
+    FH_CHECK_PTR(d->w_ih[l]);
+    FH_CHECK_PTR(d->w_hh[l]);
+    FH_CHECK_PTR(d->b_ih[l]);
+    FH_CHECK_PTR(d->b_hh[l]);
+  }
+  FH_CHECK_PTR(d->hs);
+  FH_CHECK_PTR(d->cs);
+  FH_CHECK_PTR(d->gates);
+  FH_CHECK_PTR(d->pre);
+  return FHVAE_OK;
+}
+
+template <typename T>
+static int lstm_fwd_impl(const fhvae_lstm_desc* d, hipStream_t st) {
+  const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
+  const int L = d->L;
+  const int64_t K0 = I + Ic;
+  const T* w0 = (const T*)d->w_ih[0];
+  // ---- layer-0 input projection (+ both biases): pre = [x_t || xc] . W_ih0^T + b_ih0 + b_hh0
+  {
+    GemmParams p = {};
+    int s = 0;
+    if (I > 0) p.seg[s++] = Seg{d->x, I, 1, w0, K0, 1, (int)I, 0};
+    if (Ic > 0) p.seg[s++] = Seg{d->xc, Ic, 1, w0 + I, K0, 1, (int)Ic, I > 0 ? (int)B : 0};
+    p.M = (int)(I > 0 ? T_ * B : B);
+    p.N = (int)(4 * H);
+    p.C = d->pre;
+    p.ldc = 4 * H;
+    p.bias = d->b_ih[0];
+    p.bias2 = d->b_hh[0];
+    p.splitk = 1;
+    int e = launch_gemm(p, d->dtype, st);
+    if (e) return e;
+  }
+  const int64_t pre_tstride = I > 0 ? B * 4 * H : 0;
+  T* hs = (T*)d->hs;
+  // ---- wavefront over (layer, time)
+  for (int64_t w = 0; w < T_ + L - 1; ++w) {
+    FwdJobs<T> jobs = {};
+    jobs.B = (int)B;
+    jobs.H = (int)H;
+    int nj = 0;
+    for (int l = 0; l < L; ++l) {
+      const int64_t t = w - l;
+      if (t < 0 || t >= T_) continue;
+      FwdJob<T>& J = jobs.job[nj++];
+      const int64_t lt = (int64_t)l * T_ + t;
+      if (l > 0) J.seg[0] = Seg{hs + ((int64_t)(l - 1) * T_ + t) * B * H, H, 1, d->w_ih[l], H, 1, (int)H, 0};
+      if (t > 0) J.seg[1] = Seg{hs + (lt - 1) * B * H, H, 1, d->w_hh[l], H, 1, (int)H, 0};
+      if (l == 0) {
+        J.pre = d->pre + t * pre_tstride;
+        J.pre_ld = 4 * H;
+      } else {
+        J.bias_a = d->b_ih[l];
+        J.bias_b = d->b_hh[l];
+      }
+      J.c_prev = t > 0 ? d->cs + (lt - 1) * B * H : nullptr;
+      J.c_out = d->cs + lt * B * H;
+      J.h_out = hs + lt * B * H;
+      J.gates_out = d->gates + lt * B * 4 * H;
+      if (d->hn && t == T_ - 1) {
+        J.hn_out = d->hn + (int64_t)l * H;
+        J.hn_ld = (int64_t)L * H;
+      }
+    }
+    dim3 grid((unsigned)fh_cdiv(H, 16), (unsigned)fh_cdiv(B, 64), (unsigned)nj);
+    hipLaunchKernelGGL((lstm_fwd_step_kernel<T>), grid, dim3(kThreads), 0, st, jobs);
+    int e = fh_launch_status();
+    if (e) return e;
+  }
+  return FHVAE_OK;
+}
+
+extern "C" int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream) {
+  int e = check_desc(d);
+  if (e) return e;
+  if (d->dtype == FHVAE_F32) return lstm_fwd_impl<float>(d, (hipStream_t)stream);
+  return lstm_fwd_impl<u16>(d, (hipStream_t)stream);
+}
+
+template <typename T>
+static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, hipStream_t st) {
+  const fhvae_lstm_desc* d = &bd->f;
+  const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
+  const int L = d->L;
+  const int64_t K0 = I + Ic;
+  constexpr bool kF32 = sizeof(T) == 4;
+  T* dg = (T*)bd->dgates;
+  // In f32 mode the weights are read untransposed as KM operands; in bf16 mode the transposed
+  // copies [H,4H] are KC operands.
+  for (int64_t w = 0; w < T_ + L - 1; ++w) {
+    BwdJobs<T> jobs = {};
+    jobs.B = (int)B;
+    jobs.H = (int)H;
+    int nj = 0;
+    for (int l = L - 1; l >= 0; --l) {
+      const int64_t u = w - (L - 1 - l);
+      if (u < 0 || u >= T_) continue;
+      const int64_t t = T_ - 1 - u;
+      BwdJob<T>& J = jobs.job[nj++];
+      const int64_t lt = (int64_t)l * T_ + t;
+      if (t < T_ - 1) {
+        const T* a = dg + (lt + 1) * B * 4 * H;
+        J.seg[0] = kF32 ? Seg{a, 4 * H, 1, d->w_hh[l], H, 0, (int)(4 * H), 0}
+                        : Seg{a, 4 * H, 1, d->w_hh_t[l], 4 * H, 1, (int)(4 * H), 0};
+      }
+      if (l < L - 1) {
+        const T* a = dg + ((int64_t)(l + 1) * T_ + t) * B * 4 * H;
+        J.seg[1] = kF32 ? Seg{a, 4 * H, 1, d->w_ih[l + 1], H, 0, (int)(4 * H), 0}
+                        : Seg{a, 4 * H, 1, d->w_ih_t[l + 1], 4 * H, 1, (int)(4 * H), 0};
+      }
+      if (l == L - 1 && bd->d_hs_top) {
+        J.ext = bd->d_hs_top + t * B * H;
+        J.ext_ld = H;
+      }
+      if (t == T_ - 1 && bd->d_hn) {
+        J.ext2 = bd->d_hn + (int64_t)l * H;
+        J.ext2_ld = (int64_t)L * H;
+      }
+      J.gates = d->gates + lt * B * 4 * H;
+      J.c_prev = t > 0 ? d->cs + (lt - 1) * B * H : nullptr;
+      J.c_cur = d->cs + lt * B * H;
+      J.dc = bd->dc + (int64_t)l * B * H;
+      J.first = t == T_ - 1;
+      J.dg_out = dg + lt * B * 4 * H;
+      J.dgsum = (l == 0 && Ic > 0) ? bd->dgsum : nullptr;
+    }
+    dim3 grid((unsigned)fh_cdiv(H, 32), (unsigned)fh_cdiv(B, 32), (unsigned)nj);
+    hipLaunchKernelGGL((lstm_bwd_step_kernel<T>), grid, dim3(kThreads), 0, st, jobs);
+    int e = fh_launch_status();
+    if (e) return e;
+  }
+  return FHVAE_OK;
+}
+
+// weight / bias / input gradients after the recurrence (f32 operands: dgates, hs, x are f32)
+static int lstm_param_grads_f32(const fhvae_lstm_bwd_desc* bd, const float* dg, const float* hs, const float* x,
+                                const float* xc, hipStream_t st) {
+  const fhvae_lstm_desc* d = &bd->f;
+  const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
+  const int L = d->L;
+  const int64_t K0 = I + Ic, G = 4 * H;
+  auto wgrad = [&](const float* a, int64_t lda, const float* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc,
+                   int64_t Ncols) -> int {
+    // c[G, Ncols] += a[Kc, G]^T . b[Kc, Ncols]
+    GemmParams p = {};
+    p.seg[0] = Seg{a, lda, 0, b, ldb, 0, (int)Kc, 0};
+    p.M = (int)G;
+    p.N = (int)Ncols;
+    p.C = c;
+    p.ldc = ldc;
+    p.splitk = pick_splitk(G, Ncols, Kc);
+    p.mode = p.splitk > 1 ? 2 : 1;
+    return launch_gemm(p, FHVAE_F32, st);
+  };
+  for (int l = 0; l < L; ++l) {
+    const float* dgl = dg + (int64_t)l * T_ * B * G;
+    const float* hl = hs + (int64_t)l * T_ * B * H;
+    int e;
+    if (bd->dw_hh[l] && T_ > 1) {
+      e = wgrad(dgl + B * G, G, hl, H, (T_ - 1) * B, bd->dw_hh[l], H, H);
+      if (e) return e;
+    }
+    if (bd->dw_ih[l]) {
+      if (l > 0) {
+        e = wgrad(dgl, G, hs + (int64_t)(l - 1) * T_ * B * H, H, T_ * B, bd->dw_ih[l], H, H);
+        if (e) return e;
+      } else {
+        if (I > 0) {
+          e = wgrad(dgl, G, x, I, T_ * B, bd->dw_ih[0], K0, I);
+          if (e) return e;
+        }
+        if (Ic > 0) {
+          e = wgrad(bd->dgsum, G, xc, Ic, B, bd->dw_ih[0] + I, K0, Ic);
+          if (e) return e;
+        }
+      }
+    }
+    e = launch_colsum(dgl, G, bd->db_ih[l], bd->db_hh[l], T_ * B, G, st);
+    if (e) return e;
+  }
+  return FHVAE_OK;
+}
+
+extern "C" int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* bd, void* stream) {
+  FH_CHECK_PTR(bd);
+  const fhvae_lstm_desc* d = &bd->f;
+  int e = check_desc(d);
+  if (e) return e;
+  FH_CHECK_PTR(bd->dgates);
+  FH_CHECK_PTR(bd->dc);
+  if (d->Ic > 0) FH_CHECK_PTR(bd->dgsum);
+  if (!bd->d_hs_top && !bd->d_hn) return FHVAE_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == FHVAE_F32) {
+    e = lstm_bwd_impl<float>(bd, st);
+    if (e) return e;
+    e = lstm_param_grads_f32(bd, (const float*)bd->dgates, (const float*)d->hs, (const float*)d->x,
+                             (const float*)d->xc, st);
+    if (e) return e;
+    if (bd->d_xc && d->Ic > 0) {
+      // d_xc[B,Ic] = dgsum[B,4H] . W_ih0[:, I:]   (KM operand: B(n, k) = W[k*K0 + I + n])
+      GemmParams p = {};
+      p.seg[0] = Seg{bd->dgsum, 4 * d->H, 1, (const float*)d->w_ih[0] + d->I, d->I + d->Ic, 0, (int)(4 * d->H), 0};
+      p.M = (int)d->B;
+      p.N = (int)d->Ic;
+      p.C = bd->d_xc;
+      p.ldc = d->Ic;
+      p.splitk = 1;
+      e = launch_gemm(p, FHVAE_F32, st);
+      if (e) return e;
+    }
+    return FHVAE_OK;
+  }
+  return FHVAE_ERR_DTYPE;  // bf16 backward: not in this build yet
+}

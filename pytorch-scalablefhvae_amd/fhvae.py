@@ -1,0 +1,105 @@
+"""Drop-in `fhvae.FHVAE`: the LSTM Scalable-FHVAE on the MI355X HIP kernels.
+
+The reference class is a stub (fhvae.py:4-14: constructor signature, then NotImplementedError); the
+train loop constructs and calls it exactly like SimpleFHVAE (train_model.py:400-407, :447-449), so
+the constructor and forward signatures and the 6-tuple returned are the contract.  The body is
+defined by this build (DESIGN.md "FHVAE architecture"; CPU restatement: oracle/ref_cpu.py FHVAERef):
+
+  z2 encoder : L-layer LSTM over x (B,T,F)          -> concat_l h^l_T -> Gaussian head (z2_dim)
+  z1 encoder : L-layer LSTM over [x_t || z2_sample] -> concat_l h^l_T -> Gaussian head (z1_dim)
+  decoder    : L-layer LSTM over [z1 || z2] (same input every step) -> top-layer h_t -> per-frame
+               Gaussian head (F)
+Parameters live in `*.lstm.{weight_ih_l{k},weight_hh_l{k},bias_ih_l{k},bias_hh_l{k}}` (torch.nn.LSTM
+names and default init, so a state dict moves between this module and the CPU oracle unchanged).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+import hip_binding as hb
+from fhvae_core import FHVAEBase
+from simple_fhvae import GaussianLayer
+
+
+class LSTMParams(nn.Module):
+    """Parameter container with torch.nn.LSTM's names, shapes, registration order and default init
+    (uniform(-1/sqrt(H), 1/sqrt(H)) over parameters in registration order)."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        k = 1.0 / math.sqrt(hidden_size)
+        for l in range(num_layers):
+            i = input_size if l == 0 else hidden_size
+            for name, shape in (("weight_ih", (4 * hidden_size, i)), ("weight_hh", (4 * hidden_size, hidden_size)),
+                                ("bias_ih", (4 * hidden_size,)), ("bias_hh", (4 * hidden_size,))):
+                self.register_parameter("%s_l%d" % (name, l), nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+
+    def flat(self):
+        out = []
+        for l in range(self.num_layers):
+            out += [getattr(self, "%s_l%d" % (n, l)) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        return out
+
+
+class LSTMNet(nn.Module):
+    def __init__(self, input_size: int, hus):
+        super().__init__()
+        if len(set(hus)) != 1:
+            raise ValueError("all layers of one LSTM net must share the hidden size (got %s)" % (hus,))
+        self.lstm = LSTMParams(input_size, hus[0], len(hus))
+
+    def forward(self, x_tm, xc, T):
+        """x_tm (T,B,I) time-major or None; xc (B,Ic) constant-over-time extra input or None.
+        Returns (top-layer h_t (T,B,H), concat of final h of all layers (B, L*H))."""
+        return hb.lstm_seq(x_tm, xc, T, self.lstm.flat())
+
+
+class FHVAE(FHVAEBase):
+    def __init__(self, input_size: int, z1_hus: list, z2_hus: list, z1_dim: int, z2_dim: int, x_hus: list, *,
+                 seg_len: int = 20, num_seqs=None, reference_compat=True):
+        super().__init__()
+        self.model = "fhvae"
+        self._init_common(z1_hus, z2_hus, z1_dim, z2_dim, x_hus, num_seqs, reference_compat)
+        input_size = int(input_size)
+        if input_size % seg_len:
+            raise ValueError("input_size=%d is not a multiple of seg_len=%d" % (input_size, seg_len))
+        self.seg_len = int(seg_len)         # train_model.py:120 (--seg-len, default 20)
+        self.n_feat = input_size // seg_len  # input_size = T*F, train_model.py:398
+        F_ = self.n_feat
+        # same construction order as SimpleFHVAE (simple_fhvae.py:31-36)
+        self.z1_pre_encoder = LSTMNet(F_ + self.z2_dim, self.z1_hus)
+        self.z2_pre_encoder = LSTMNet(F_, self.z2_hus)
+        self.z1_gauss_layer = GaussianLayer(sum(self.z1_hus), self.z1_dim)
+        self.z2_gauss_layer = GaussianLayer(sum(self.z2_hus), self.z2_dim)
+        self.pre_decoder = LSTMNet(self.z1_dim + self.z2_dim, self.x_hus)
+        self.dec_gauss_layer = GaussianLayer(self.x_hus[-1], F_)
+        self._maybe_create_table()
+
+    def mu2_lookup(self, mu_idx, z2_dim, num_seqs, init_std: float = 1.0, mu2_table=None):
+        table = mu2_table if mu2_table is not None else self._table(num_seqs, mu_idx.device)
+        return table, hb.mu2_gather(table, mu_idx)
+
+    def forward(self, x: torch.Tensor, mu_idx: torch.Tensor, num_seqs: int, num_segs, *, mu2_table=None, eps=None):
+        x, mu_idx, num_segs = self._prep_inputs(x, mu_idx, num_segs)
+        B, T, F_ = x.shape
+        if F_ != self.n_feat:
+            raise ValueError("x has %d features per frame, model was built for %d" % (F_, self.n_feat))
+        mu2_table, mu2 = self.mu2_lookup(mu_idx, self.z2_dim, num_seqs, mu2_table=mu2_table)
+        e2, e1 = self._draw(eps, B, x.device)
+
+        x_tm = hb.to_time_major(x)  # (T,B,F): contiguous per-step tiles for the step-fused cells
+        _, hn2 = self.z2_pre_encoder(x_tm, None, T)
+        z2_mu, z2_logvar, z2_sample = self.z2_gauss_layer(hn2, e2)
+        _, hn1 = self.z1_pre_encoder(x_tm, z2_sample, T)
+        z1_mu, z1_logvar, z1_sample = self.z1_gauss_layer(hn1, e1)
+        hs_top, _ = self.pre_decoder(None, torch.cat([z1_sample, z2_sample], dim=-1), T)
+        H = hs_top.shape[-1]
+        x_mu, x_logvar, _ = self.dec_gauss_layer(hs_top.reshape(T * B, H), sample=False)  # (T*B, F) time-major
+
+        layout = (B, T, F_, (F_, B * F_), (F_, B * F_))  # x_tm and x_mu/x_logvar are all time-major
+        return self._tail(x_tm, layout, x_mu, x_logvar, (z1_mu, z1_logvar), (z2_mu, z2_logvar), mu2, mu2_table, mu_idx,
+                          num_segs)

@@ -1,0 +1,95 @@
+"""Host-side logic shared by the two drop-in modules (`simple_fhvae.SimpleFHVAE`, `fhvae.FHVAE`):
+the persistent mu2 table, the injected-draw plumbing and the loss tail that follows the three nets
+(simple_fhvae.py:86-88 and :105-124).  All arithmetic is delegated to hip_binding (HIP kernels)."""
+from __future__ import annotations
+
+import warnings
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import hip_binding as hb
+
+PZ1_LOGVAR = np.log(1.0 ** 2).astype(np.float32)   # simple_fhvae.py:22
+PMU2_LOGVAR = np.log(1.0 ** 2).astype(np.float32)  # simple_fhvae.py:23
+PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)   # simple_fhvae.py:88
+
+
+class FHVAEBase(nn.Module):
+    """Common constructor surface and loss tail.
+
+    Positional constructor/forward signatures are the reference's (simple_fhvae.py:9-17,71-73;
+    fhvae.py:5-13).  Keyword-only additions:
+      num_seqs          -- create the persistent, learnable mu2 table (S, z2_dim) ~ N(0,1) at
+                           construction (the reference re-draws a throw-away table on every forward,
+                           simple_fhvae.py:51).  If omitted the table is created at the
+                           first forward (and an optimizer built earlier will not see it).
+      reference_compat  -- True (default): forward values AND gradients follow the reference
+                           literally: `.detach()` on the decoder outputs and on mu2 inside the bound
+                           (simple_fhvae.py:107,114) and `log_qy` = +CE (:122).  False: the intended
+                           objective (decoder trained, `log_qy` = -CE).
+    forward() keyword-only additions (parity injection): `mu2_table`, `eps=(eps_z2, eps_z1)`.
+    """
+
+    def _init_common(self, z1_hus, z2_hus, z1_dim, z2_dim, x_hus, num_seqs, reference_compat):
+        # hus arrive as strings from the reference CLI (nargs=2 without type, train_model.py:146-168)
+        self.z1_hus = [int(h) for h in z1_hus]
+        self.z2_hus = [int(h) for h in z2_hus]
+        self.x_hus = [int(h) for h in x_hus]
+        self.z1_dim = int(z1_dim)
+        self.z2_dim = int(z2_dim)
+        self.pz1 = [0.0, PZ1_LOGVAR]
+        self.pmu2 = [0.0, PMU2_LOGVAR]
+        self.reference_compat = bool(reference_compat)
+        self._init_num_seqs = num_seqs
+
+    def _maybe_create_table(self):
+        # called at the END of __init__ so that the nets' default init consumes the RNG first
+        # (same draws as the reference constructor under the same seed)
+        if self._init_num_seqs is not None:
+            self.mu2_table = nn.Parameter(torch.empty(int(self._init_num_seqs), self.z2_dim).normal_(0.0, 1.0))
+        else:
+            self.register_parameter("mu2_table", None)
+
+    def _table(self, num_seqs: int, device) -> torch.Tensor:
+        if self.mu2_table is None:
+            warnings.warn(
+                "mu2_table created lazily at the first forward; optimizers built before this call do not "
+                "contain it (pass num_seqs= to the constructor)")
+            self.mu2_table = nn.Parameter(torch.empty(int(num_seqs), self.z2_dim, device=device).normal_(0.0, 1.0))
+        if self.mu2_table.shape[0] != int(num_seqs):
+            raise ValueError("num_seqs=%d does not match the mu2 table (%d rows)" % (num_seqs, self.mu2_table.shape[0]))
+        return self.mu2_table
+
+    @staticmethod
+    def _prep_inputs(x, mu_idx, num_segs):
+        if not x.is_cuda:
+            raise RuntimeError("FHVAE (HIP path) needs the model and inputs on a MI355X device; no CPU fallback")
+        if x.dtype != torch.float32:
+            raise RuntimeError("the HIP path computes in float32/bf16; got input dtype %s "
+                               "(the reference's model.double() at train_model.py:438 is not supported)" % x.dtype)
+        dev = x.device
+        mu_idx = torch.as_tensor(mu_idx).to(device=dev, dtype=torch.int64).contiguous()
+        if isinstance(num_segs, torch.Tensor):
+            num_segs = num_segs.to(device=dev, dtype=torch.int64).contiguous()
+        return x.contiguous(), mu_idx, num_segs
+
+    def _draw(self, eps, B, device):
+        if eps is not None:
+            return eps[0].to(device), eps[1].to(device)
+        # reference draw order after the table: eps_z2 then eps_z1
+        e2 = torch.randn(B, self.z2_dim, device=device)
+        e1 = torch.randn(B, self.z1_dim, device=device)
+        return e2, e1
+
+    def _tail(self, x_like, layout, x_mu, x_lv, z1, z2, mu2, table, mu_idx, num_segs):
+        """simple_fhvae.py:105-124 on the HIP kernels."""
+        rc = self.reference_compat
+        lb, lpx, nk1, nk2, lpm = hb.elbo(x_like, x_mu, x_lv, z1[0], z1[1], z2[0], z2[1], mu2, num_segs, layout, rc)
+        ce = hb.disc_lse(z2[0], table, mu_idx)
+        log_qy = ce if rc else -ce
+        self.qz2_x = [z2[0], z2[1]]      # read by estimate_mu2_dict, utils.py:52
+        self.pz2 = [mu2, PZ2_LOGVAR]     # utils.py:58
+        return lb, log_qy, lpx, nk1, nk2, lpm

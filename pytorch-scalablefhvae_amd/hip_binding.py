@@ -1,0 +1,492 @@
+"""ctypes binding of libfhvae_hip.so (C ABI: include/fhvae_hip.h) + autograd wrappers.
+
+This is the only place where Python touches the HIP library.  PyTorch is used for device memory
+(the caching allocator, so everything is hipGraph-capturable), the current stream and autograd
+bookkeeping; all arithmetic of the hot path runs in the hand-written kernels.  There is NO CPU or
+eager-PyTorch fallback: if the library is missing or a tensor is not on a GPU, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
+
+F32, BF16 = 0, 1
+MAX_LAYERS = 4
+#: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
+PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
+INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
+
+_vp, _i64, _i32, _f32, _f64 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_double
+
+
+class LstmDesc(C.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("L", _i32),
+        ("B", _i64), ("T", _i64), ("I", _i64), ("Ic", _i64), ("H", _i64),
+        ("x", _vp), ("xc", _vp),
+        ("w_ih", _vp * MAX_LAYERS), ("w_hh", _vp * MAX_LAYERS),
+        ("b_ih", _vp * MAX_LAYERS), ("b_hh", _vp * MAX_LAYERS),
+        ("w_ih_t", _vp * MAX_LAYERS), ("w_hh_t", _vp * MAX_LAYERS),
+        ("hs", _vp), ("cs", _vp), ("gates", _vp), ("hn", _vp), ("pre", _vp),
+    ]
+
+
+class LstmBwdDesc(C.Structure):
+    _fields_ = [
+        ("f", LstmDesc),
+        ("d_hs_top", _vp), ("d_hn", _vp),
+        ("dgates", _vp), ("dgsum", _vp), ("dc", _vp),
+        ("dw_ih", _vp * MAX_LAYERS), ("dw_hh", _vp * MAX_LAYERS),
+        ("db_ih", _vp * MAX_LAYERS), ("db_hh", _vp * MAX_LAYERS),
+        ("d_xc", _vp), ("x_f32", _vp), ("xc_f32", _vp),
+    ]
+
+
+class ElboDesc(C.Structure):
+    _fields_ = [
+        ("B", _i64), ("T", _i64), ("F", _i64), ("D1", _i64), ("D2", _i64),
+        ("x", _vp), ("x_sb", _i64), ("x_st", _i64),
+        ("x_mu", _vp), ("x_lv", _vp), ("xo_sb", _i64), ("xo_st", _i64),
+        ("z1_mu", _vp), ("z1_lv", _vp), ("z2_mu", _vp), ("z2_lv", _vp), ("mu2", _vp),
+        ("num_segs", _vp), ("nsegs_scalar", _f64),
+        ("lower_bound", _vp), ("log_px_z", _vp), ("neg_kld_z1", _vp), ("neg_kld_z2", _vp), ("log_pmu2", _vp),
+    ]
+
+
+class ElboBwdDesc(C.Structure):
+    _fields_ = [
+        ("f", ElboDesc),
+        ("g_lower_bound", _vp), ("g_log_px_z", _vp), ("g_neg_kld_z1", _vp), ("g_neg_kld_z2", _vp), ("g_log_pmu2", _vp),
+        ("reference_detach", _i32),
+        ("d_x_mu", _vp), ("d_x_lv", _vp), ("d_z1_mu", _vp), ("d_z1_lv", _vp), ("d_z2_mu", _vp), ("d_z2_lv", _vp),
+        ("d_mu2", _vp),
+    ]
+
+
+#: every symbol include/fhvae_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "fhvae_abi_version": (C.c_int, []),
+    "fhvae_strerror": (C.c_char_p, [C.c_int]),
+    "fhvae_linear_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i64, C.c_int, C.c_int, _vp]),
+    "fhvae_linear_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
+                                   _i64, C.c_int, C.c_int, _vp]),
+    "fhvae_gauss_head_reparam_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int,
+                                               _vp]),
+    "fhvae_gauss_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
+    "fhvae_lstm_seq_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), _vp]),
+    "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "fhvae_mu2_gather_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_elbo_fwd": (C.c_int, [C.POINTER(ElboDesc), _vp]),
+    "fhvae_elbo_bwd": (C.c_int, [C.POINTER(ElboBwdDesc), _vp]),
+    "fhvae_disc_lse_ws_bytes": (_i64, [_i64, _i64]),
+    "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "fhvae_to_time_major": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
+    "fhvae_cast_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+}
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the HIP library and bind every declared symbol.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "libfhvae_hip.so is not built (%s). Run `python pytorch-scalablefhvae_amd/build_ext.py` "
+            "(or __graft_entry__.build()). There is no CPU fallback." % path
+        )
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fhvae_abi_version() != 1:
+        raise RuntimeError("libfhvae_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        msg = load_library().fhvae_strerror(code).decode()
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg, code))
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "fhvae HIP op called with a CPU tensor: the hot path has no CPU fallback "
+                "(move the model and inputs to a MI355X device)"
+            )
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise RuntimeError("fhvae HIP ops take float32 tensors (got %s)" % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# raw (no-autograd) calls used by the Functions below and by tests
+# ---------------------------------------------------------------------------------------------
+def raw_linear_fwd(x, w, b, relu=False):
+    lib = load_library()
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _check(lib.fhvae_linear_fwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(b), _p(y), N, None, M, K, N, int(relu), F32,
+                                _stream()), "fhvae_linear_fwd")
+    return y
+
+
+def raw_linear_bwd(x, w, y, dy, relu, need_dx=True, need_dw=True, need_db=True, dx_out=None):
+    lib = load_library()
+    M, K = x.shape
+    N = w.shape[0]
+    dev = x.device
+    masked = torch.empty(M, N, device=dev, dtype=torch.float32) if relu else None
+    acc = dx_out is not None
+    dx = dx_out if acc else (torch.empty(M, K, device=dev, dtype=torch.float32) if need_dx else None)
+    dw = torch.zeros(N, K, device=dev, dtype=torch.float32) if need_dw else None
+    db = torch.zeros(N, device=dev, dtype=torch.float32) if need_db else None
+    _check(lib.fhvae_linear_bwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(y), N if y is not None else 0, _p(dy),
+                                dy.stride(0), _p(masked), _p(dx), K, _p(dw), K, _p(db), M, K, N, int(relu), int(acc),
+                                _stream()), "fhvae_linear_bwd")
+    return dx, dw, db
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd Functions
+# ---------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) -- nn.Linear(+ReLU), simple_fhvae.py:127-134."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        _need_gpu(x, w, b)
+        x, w, b = _f32c(x), _f32c(w), _f32c(b)
+        y = raw_linear_fwd(x, w, b, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx, dw, db = raw_linear_bwd(x, w, y, dy, ctx.relu, need_dx=ctx.needs_input_grad[0],
+                                    need_dw=ctx.needs_input_grad[1], need_db=ctx.needs_input_grad[2])
+        return dx, dw, db, None
+
+
+def linear(x, w, b, relu=False):
+    return _Linear.apply(x, w, b, bool(relu))
+
+
+class _GaussHead(torch.autograd.Function):
+    """(mu, logvar, sample) = GaussianLayer(h) with an injected eps -- simple_fhvae.py:193-216."""
+
+    @staticmethod
+    def forward(ctx, h, w_mu, b_mu, w_lv, b_lv, eps):
+        _need_gpu(h, w_mu, b_mu, w_lv, b_lv, eps)
+        lib = load_library()
+        h, w_mu, b_mu, w_lv, b_lv = _f32c(h), _f32c(w_mu), _f32c(b_mu), _f32c(w_lv), _f32c(b_lv)
+        M, K = h.shape
+        D = w_mu.shape[0]
+        mu = torch.empty(M, D, device=h.device, dtype=torch.float32)
+        lv = torch.empty_like(mu)
+        if eps is not None:
+            eps = _f32c(eps)
+            smp = torch.empty_like(mu)
+        else:
+            smp = None
+        _check(lib.fhvae_gauss_head_reparam_fwd(_p(h), h.stride(0), _p(w_mu), _p(w_lv), _p(b_mu), _p(b_lv), _p(eps), _p(mu),
+                                                _p(lv), _p(smp), M, K, D, F32, _stream()), "fhvae_gauss_head_reparam_fwd")
+        ctx.save_for_backward(h, w_mu, w_lv, eps, lv)
+        if smp is None:
+            smp = mu.new_zeros(())  # placeholder output, never differentiable
+            ctx.mark_non_differentiable(smp)
+        return mu, lv, smp
+
+    @staticmethod
+    def backward(ctx, d_mu, d_lv, d_s):
+        lib = load_library()
+        h, w_mu, w_lv, eps, lv = ctx.saved_tensors
+        if eps is None:
+            d_s = None
+        M, D = lv.shape
+        g_mu = torch.empty_like(lv)
+        g_lv = torch.empty_like(lv)
+        d_mu = _f32c(d_mu) if d_mu is not None else None
+        d_lv = _f32c(d_lv) if d_lv is not None else None
+        d_s = _f32c(d_s) if d_s is not None else None
+        _check(lib.fhvae_gauss_reparam_bwd(_p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), _p(g_mu), _p(g_lv), M * D, _stream()),
+               "fhvae_gauss_reparam_bwd")
+        need_dh = ctx.needs_input_grad[0]
+        dh, dw_mu, db_mu = raw_linear_bwd(h, w_mu, None, g_mu, False, need_dx=need_dh)
+        _, dw_lv, db_lv = raw_linear_bwd(h, w_lv, None, g_lv, False, need_dx=need_dh, dx_out=dh if need_dh else None)
+        return dh, dw_mu, db_mu, dw_lv, db_lv, None
+
+
+def gauss_head(h, w_mu, b_mu, w_lv, b_lv, eps):
+    mu, lv, smp = _GaussHead.apply(h, w_mu, b_mu, w_lv, b_lv, eps)
+    return mu, lv, (smp if eps is not None else None)
+
+
+def to_time_major(x: torch.Tensor) -> torch.Tensor:
+    """(B,T,F) -> (T,B,F) copy (input data: no gradient)."""
+    _need_gpu(x)
+    lib = load_library()
+    x = _f32c(x.detach())
+    B, T, F_ = x.shape
+    out = torch.empty(T, B, F_, device=x.device, dtype=torch.float32)
+    _check(lib.fhvae_to_time_major(_p(x), _p(out), None, B, T, F_, F32, _stream()), "fhvae_to_time_major")
+    return out
+
+
+class _LstmSeq(torch.autograd.Function):
+    """Multi-layer LSTM over the whole segment (K1).  Inputs: x_tm (T,B,I) or None, xc (B,Ic) or None,
+    then per layer w_ih, w_hh, b_ih, b_hh.  Outputs: hs_top (T,B,H) and hn (B, L*H)."""
+
+    @staticmethod
+    def forward(ctx, x_tm, xc, T, *params):
+        lib = load_library()
+        _need_gpu(x_tm, xc, *params)
+        L = len(params) // 4
+        assert len(params) == 4 * L and 1 <= L <= MAX_LAYERS
+        params = [_f32c(p) for p in params]
+        H = params[1].shape[1]
+        x_tm = _f32c(x_tm) if x_tm is not None else None
+        xc = _f32c(xc) if xc is not None else None
+        I = x_tm.shape[2] if x_tm is not None else 0
+        Ic = xc.shape[1] if xc is not None else 0
+        B = x_tm.shape[1] if x_tm is not None else xc.shape[0]
+        if x_tm is not None:
+            assert x_tm.shape[0] == T
+        assert params[0].shape == (4 * H, I + Ic), (params[0].shape, H, I, Ic)
+        dev = params[0].device
+        f32 = dict(device=dev, dtype=torch.float32)
+        hs = torch.empty(L, T, B, H, **f32)
+        cs = torch.empty(L, T, B, H, **f32)
+        gates = torch.empty(L, T, B, 4 * H, **f32)
+        hn = torch.empty(B, L * H, **f32)
+        pre = torch.empty((T if I > 0 else 1), B, 4 * H, **f32)
+        d = LstmDesc()
+        d.dtype, d.L, d.B, d.T, d.I, d.Ic, d.H = F32, L, B, T, I, Ic, H
+        d.x, d.xc = _p(x_tm), _p(xc)
+        for l in range(L):
+            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_p(params[4 * l + k]) for k in range(4))
+        d.hs, d.cs, d.gates, d.hn, d.pre = _p(hs), _p(cs), _p(gates), _p(hn), _p(pre)
+        _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")
+        ctx.dims = (L, B, T, I, Ic, H)
+        ctx.save_for_backward(x_tm, xc, hs, cs, gates, *params)
+        return hs[L - 1], hn
+
+    @staticmethod
+    def backward(ctx, d_hs_top, d_hn):
+        lib = load_library()
+        L, B, T, I, Ic, H = ctx.dims
+        x_tm, xc, hs, cs, gates = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        dev = hs.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        if d_hs_top is None and d_hn is None:
+            return (None,) * (3 + 4 * L)
+        d_hs_top = _f32c(d_hs_top) if d_hs_top is not None else None
+        d_hn = _f32c(d_hn) if d_hn is not None else None
+        bd = LstmBwdDesc()
+        d = bd.f
+        d.dtype, d.L, d.B, d.T, d.I, d.Ic, d.H = F32, L, B, T, I, Ic, H
+        d.x, d.xc = _p(x_tm), _p(xc)
+        for l in range(L):
+            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_p(params[4 * l + k]) for k in range(4))
+        pre = torch.empty(1, **f32)  # not used by the backward, must be non-NULL
+        d.hs, d.cs, d.gates, d.hn, d.pre = _p(hs), _p(cs), _p(gates), None, _p(pre)
+        dgates = torch.empty(L, T, B, 4 * H, **f32)
+        dgsum = torch.empty(B, 4 * H, **f32) if Ic > 0 else None
+        dc = torch.empty(L, B, H, **f32)
+        grads = [torch.zeros_like(p) for p in params]
+        d_xc = torch.empty(B, Ic, **f32) if (Ic > 0 and ctx.needs_input_grad[1]) else None
+        bd.d_hs_top, bd.d_hn = _p(d_hs_top), _p(d_hn)
+        bd.dgates, bd.dgsum, bd.dc = _p(dgates), _p(dgsum), _p(dc)
+        for l in range(L):
+            bd.dw_ih[l], bd.dw_hh[l], bd.db_ih[l], bd.db_hh[l] = (_p(grads[4 * l + k]) for k in range(4))
+        bd.d_xc = _p(d_xc)
+        _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
+        return (None, d_xc, None, *grads)
+
+
+def lstm_seq(x_tm, xc, T, params: Sequence[torch.Tensor]):
+    return _LstmSeq.apply(x_tm, xc, int(T), *params)
+
+
+class _Mu2Gather(torch.autograd.Function):
+    """mu2 = table[idx] -- simple_fhvae.py:53."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        _need_gpu(table, idx)
+        lib = load_library()
+        table = _f32c(table)
+        S, D = table.shape
+        B = idx.shape[0]
+        out = torch.empty(B, D, device=table.device, dtype=torch.float32)
+        _check(lib.fhvae_mu2_gather_fwd(_p(table), _p(idx), _p(out), B, S, D, None, _stream()), "fhvae_mu2_gather_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (S, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dmu2):
+        lib = load_library()
+        (idx,) = ctx.saved_tensors
+        S, D = ctx.shape
+        dmu2 = _f32c(dmu2)
+        dt = torch.zeros(S, D, device=dmu2.device, dtype=torch.float32)
+        _check(lib.fhvae_mu2_gather_bwd(_p(dmu2), _p(idx), _p(dt), idx.shape[0], S, D, _stream()), "fhvae_mu2_gather_bwd")
+        return dt, None
+
+
+def mu2_gather(table, idx):
+    return _Mu2Gather.apply(table, idx)
+
+
+def _fill_elbo_desc(d: ElboDesc, x, x_strides, x_mu, x_lv, xo_strides, z1_mu, z1_lv, z2_mu, z2_lv, mu2, num_segs, B, T, F_):
+    d.B, d.T, d.F, d.D1, d.D2 = B, T, F_, z1_mu.shape[1], z2_mu.shape[1]
+    d.x, (d.x_sb, d.x_st) = _p(x), x_strides
+    d.x_mu, d.x_lv, (d.xo_sb, d.xo_st) = _p(x_mu), _p(x_lv), xo_strides
+    d.z1_mu, d.z1_lv, d.z2_mu, d.z2_lv, d.mu2 = _p(z1_mu), _p(z1_lv), _p(z2_mu), _p(z2_lv), _p(mu2)
+    if isinstance(num_segs, torch.Tensor):
+        d.num_segs, d.nsegs_scalar = _p(num_segs), 0.0
+    else:
+        d.num_segs, d.nsegs_scalar = None, float(num_segs)
+
+
+class _Elbo(torch.autograd.Function):
+    """Fused lower bound (K3) -- simple_fhvae.py:105-116.  `layout` = (B,T,F, x strides, x_mu strides)."""
+
+    @staticmethod
+    def forward(ctx, x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2, num_segs, layout, reference_detach):
+        _need_gpu(x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2)
+        lib = load_library()
+        B, T, F_, xs, xos = layout
+        ts = [_f32c(t) for t in (x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2)]
+        if isinstance(num_segs, torch.Tensor):
+            num_segs = num_segs.to(device=ts[0].device, dtype=torch.int64).contiguous()
+        outs = [torch.empty(B, device=ts[0].device, dtype=torch.float32) for _ in range(5)]
+        d = ElboDesc()
+        _fill_elbo_desc(d, ts[0], xs, ts[1], ts[2], xos, *ts[3:], num_segs, B, T, F_)
+        d.lower_bound, d.log_px_z, d.neg_kld_z1, d.neg_kld_z2, d.log_pmu2 = (_p(o) for o in outs)
+        _check(lib.fhvae_elbo_fwd(C.byref(d), _stream()), "fhvae_elbo_fwd")
+        ctx.layout, ctx.detach = layout, bool(reference_detach)
+        ctx.nsegs = num_segs
+        ctx.save_for_backward(*ts)
+        if reference_detach:  # reference: log_px_z and log_pmu2 carry no gradient (simple_fhvae.py:107,114)
+            ctx.mark_non_differentiable(outs[1], outs[4])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_lb, g_px, g_k1, g_k2, g_pm):
+        lib = load_library()
+        ts = ctx.saved_tensors
+        B, T, F_, xs, xos = ctx.layout
+        bd = ElboBwdDesc()
+        _fill_elbo_desc(bd.f, ts[0], xs, ts[1], ts[2], xos, *ts[3:], ctx.nsegs, B, T, F_)
+        gs = [_f32c(g) if g is not None else None for g in (g_lb, g_px, g_k1, g_k2, g_pm)]
+        if ctx.detach:
+            gs[1] = gs[4] = None
+        bd.g_lower_bound, bd.g_log_px_z, bd.g_neg_kld_z1, bd.g_neg_kld_z2, bd.g_log_pmu2 = (_p(g) for g in gs)
+        bd.reference_detach = int(ctx.detach)
+        need_x = not ctx.detach
+        d_xmu = torch.empty_like(ts[1]) if need_x else None
+        d_xlv = torch.empty_like(ts[2]) if need_x else None
+        dz = [torch.empty_like(t) for t in ts[3:8]]
+        bd.d_x_mu, bd.d_x_lv = _p(d_xmu), _p(d_xlv)
+        bd.d_z1_mu, bd.d_z1_lv, bd.d_z2_mu, bd.d_z2_lv, bd.d_mu2 = (_p(t) for t in dz)
+        _check(lib.fhvae_elbo_bwd(C.byref(bd), _stream()), "fhvae_elbo_bwd")
+        return (None, d_xmu, d_xlv, *dz, None, None, None)
+
+
+def elbo(x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2, num_segs, layout, reference_detach):
+    return _Elbo.apply(x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2, num_segs, layout, bool(reference_detach))
+
+
+def raw_disc_fwd(q, table, idx, row0=0, want_ce=True):
+    lib = load_library()
+    B, D = q.shape
+    S = table.shape[0]
+    dev = q.device
+    ws = torch.empty(max(int(lib.fhvae_disc_lse_ws_bytes(B, S)), 8), device=dev, dtype=torch.uint8)
+    rmax, rsum, tgt, lse = (torch.empty(B, device=dev, dtype=torch.float32) for _ in range(4))
+    ce = torch.empty((), device=dev, dtype=torch.float32) if want_ce else None
+    _check(lib.fhvae_disc_lse_fwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(tgt), _p(lse), _p(ce),
+                                  _p(ws), B, S, D, _stream()), "fhvae_disc_lse_fwd")
+    return rmax, rsum, tgt, lse, ce
+
+
+def raw_disc_bwd(q, table, idx, lse, g_scale, g_mul, row0=0, need_dq=True, need_dt=True):
+    lib = load_library()
+    B, D = q.shape
+    S = table.shape[0]
+    dq = torch.empty(B, D, device=q.device, dtype=torch.float32) if need_dq else None
+    dt = torch.zeros(S, D, device=q.device, dtype=torch.float32) if need_dt else None
+    _check(lib.fhvae_disc_lse_bwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(lse), _p(g_scale), float(g_mul), _p(dq),
+                                  _p(dt), None, B, S, D, _stream()), "fhvae_disc_lse_bwd")
+    return dq, dt
+
+
+class _DiscLse(torch.autograd.Function):
+    """log_qy = CrossEntropy(-(q - table)^2 / (2 var), idx), mean over the batch (K5) --
+    simple_fhvae.py:119-122, without the (B,S,D) temporaries."""
+
+    @staticmethod
+    def forward(ctx, q, table, idx):
+        _need_gpu(q, table, idx)
+        q, table = _f32c(q), _f32c(table)
+        _, _, _, lse, ce = raw_disc_fwd(q, table, idx)
+        ctx.save_for_backward(q, table, idx, lse)
+        return ce
+
+    @staticmethod
+    def backward(ctx, g):
+        q, table, idx, lse = ctx.saved_tensors
+        g = _f32c(g).reshape(1)
+        dq, dt = raw_disc_bwd(q, table, idx, lse, g, 1.0 / q.shape[0], need_dq=ctx.needs_input_grad[0],
+                              need_dt=ctx.needs_input_grad[1])
+        return dq, dt, None
+
+
+def disc_lse(q, table, idx):
+    return _DiscLse.apply(q, table, idx)
+
+
+def adam_step_(p, g, m, v, step_dev, lr, beta1, beta2, eps, grad_scale=1.0, p_lp=None):
+    """In-place fused Adam on flat f32 views (train_model.py:409-411)."""
+    lib = load_library()
+    _need_gpu(p, g, m, v, step_dev)
+    n = p.numel()
+    _check(lib.fhvae_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, lr, beta1, beta2, eps, grad_scale, _p(step_dev),
+                               _stream()), "fhvae_adam_step")

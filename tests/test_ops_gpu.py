@@ -1,0 +1,240 @@
+"""GPU parity tests of each C-ABI op (through hip_binding -> libfhvae_hip.so) against the CPU oracle
+(oracle/ref_cpu.py) on the same seeded inputs.  Tolerance: 1e-4 relative fp32 (BASELINE.json north_star),
+applied as rtol=1e-4 with an absolute floor of 1e-4 x the tensor's max magnitude."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R
+
+
+@pytest.fixture(scope="module")
+def hb():
+    import build_ext
+
+    build_ext.build(verbose=False)
+    import hip_binding
+
+    hip_binding.load_library()
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return hip_binding
+
+
+def close(got, want, rtol=1e-4, what=""):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(want.abs().max().item(), 1e-30)
+    torch.testing.assert_close(got, want, rtol=rtol, atol=rtol * scale, msg=lambda m: "%s: %s" % (what, m))
+
+
+def dev(t):
+    return t.cuda()
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(8, 48, 16, True), (64, 1600, 128, True), (256, 1616, 128, False), (5, 7, 3, True),
+                                        (300, 130, 70, False), (64, 32, 1600, False)])
+def test_linear_fwd_bwd(hb, M, K, N, relu):
+    torch.manual_seed(M + K)
+    x = torch.randn(M, K, requires_grad=True)
+    w = (torch.randn(N, K) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, requires_grad=True)
+    y = torch.nn.functional.linear(x, w, b)
+    y = torch.relu(y) if relu else y
+    g = torch.randn(M, N)
+    y.backward(g)
+    xd, wd, bd = (dev(t.detach()).requires_grad_(True) for t in (x, w, b))
+    yd = hb.linear(xd, wd, bd, relu)
+    yd.backward(dev(g))
+    close(yd, y, what="y")
+    close(xd.grad, x.grad, what="dx")
+    close(wd.grad, w.grad, what="dw")
+    close(bd.grad, b.grad, what="db")
+
+
+def test_gauss_head(hb):
+    torch.manual_seed(1)
+    M, K, D = 37, 96, 16
+    h = torch.randn(M, K, requires_grad=True)
+    wm, wl = (torch.randn(D, K) * 0.1).requires_grad_(True), (torch.randn(D, K) * 0.1).requires_grad_(True)
+    bm, bl = torch.randn(D, requires_grad=True), torch.randn(D, requires_grad=True)
+    eps = torch.randn(M, D)
+    mu, lv = torch.nn.functional.linear(h, wm, bm), torch.nn.functional.linear(h, wl, bl)
+    s = R.gauss_sample(mu, lv, eps)
+    gm, gl, gs = torch.randn(M, D), torch.randn(M, D), torch.randn(M, D)
+    (mu * gm + lv * gl + s * gs).sum().backward()
+    args = [dev(t.detach()).requires_grad_(True) for t in (h, wm, bm, wl, bl)]
+    mud, lvd, sd = hb.gauss_head(*args, dev(eps))
+    (mud * dev(gm) + lvd * dev(gl) + sd * dev(gs)).sum().backward()
+    for got, want, n in ((mud, mu, "mu"), (lvd, lv, "lv"), (sd, s, "sample")):
+        close(got, want, what=n)
+    for a, r, n in zip(args, (h, wm, bm, wl, bl), "h wm bm wl bl".split()):
+        close(a.grad, r.grad, what="d" + n)
+    # no-sample form (decoder head)
+    mud2, lvd2, none = hb.gauss_head(*[a.detach() for a in args], None)
+    assert none is None
+    close(mud2, mu, what="mu(nosample)")
+
+
+@pytest.mark.parametrize("B,T,I,Ic,H,L", [(5, 4, 6, 0, 8, 2), (5, 4, 6, 4, 8, 2), (7, 3, 0, 8, 16, 1), (70, 20, 80, 0, 64, 2),
+                                          (33, 20, 80, 32, 48, 2), (64, 20, 0, 64, 256, 2)])
+def test_lstm_seq_vs_torch_lstm(hb, B, T, I, Ic, H, L):
+    torch.manual_seed(B * 31 + H)
+    lstm = torch.nn.LSTM(I + Ic, H, L, batch_first=True)
+    x = torch.randn(B, T, I) if I else None
+    xc = torch.randn(B, Ic, requires_grad=True) if Ic else None
+    parts = ([x] if I else []) + ([xc[:, None, :].expand(B, T, Ic)] if Ic else [])
+    out, (hn, _) = lstm(torch.cat(parts, -1))
+    hn_cat = torch.cat([hn[l] for l in range(L)], -1)
+    g_out, g_hn = torch.randn(B, T, H), torch.randn(B, L * H)
+    ((out * g_out).sum() + (hn_cat * g_hn).sum()).backward()
+
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    params = [dev(getattr(lstm, n).detach()).requires_grad_(True) for n in names]
+    x_tm = dev(x.transpose(0, 1).contiguous()) if I else None
+    xcd = dev(xc.detach()).requires_grad_(True) if Ic else None
+    hs_top, hnd = hb.lstm_seq(x_tm, xcd, T, params)
+    ((hs_top * dev(g_out.transpose(0, 1).contiguous())).sum() + (hnd * dev(g_hn)).sum()).backward()
+    close(hs_top.transpose(0, 1), out, what="hs_top")
+    close(hnd, hn_cat, what="hn")
+    for p, n in zip(params, names):
+        close(p.grad, getattr(lstm, n).grad, what="d" + n)
+    if Ic:
+        close(xcd.grad, xc.grad, what="dxc")
+
+
+def test_to_time_major(hb):
+    x = torch.randn(6, 5, 12)
+    close(hb.to_time_major(dev(x)), x.transpose(0, 1).contiguous(), rtol=0)
+
+
+@pytest.mark.parametrize("detach", [True, False])
+@pytest.mark.parametrize("B,T,F,D,tm", [(8, 4, 8, 16, False), (64, 20, 80, 32, True), (5, 3, 7, 4, False), (260, 20, 80, 16, True)])
+def test_elbo_fwd_bwd(hb, B, T, F, D, tm, detach):
+    torch.manual_seed(B + D)
+    x = torch.randn(B, T, F)
+    xm = torch.randn(B, T, F, requires_grad=True)
+    xl = (torch.randn(B, T, F) * 0.5).requires_grad_(True)
+    z = [torch.randn(B, D, requires_grad=True) for _ in range(5)]  # z1_mu z1_lv z2_mu z2_lv mu2
+    ns = torch.randint(3, 200, (B,))
+    outs = R.elbo_terms(x, xm, xl, z[0], z[1], z[2], z[3], z[4], ns, reference_detach=detach)
+    gw = [torch.randn(B) for _ in range(5)]
+    sum((o * g).sum() for o, g in zip(outs, gw) if o.requires_grad).backward()
+
+    def lay(t):  # batch-major (B,T,F) or time-major (T,B,F) copy on the device
+        return dev(t.detach().transpose(0, 1).contiguous() if tm else t.detach())
+
+    xd, xmd, xld = lay(x), lay(xm).requires_grad_(True), lay(xl).requires_grad_(True)
+    zd = [dev(t.detach()).requires_grad_(True) for t in z]
+    strides = (F, B * F) if tm else (T * F, F)
+    got = hb.elbo(xd, xmd, xld, *zd, dev(ns), (B, T, F, strides, strides), detach)
+    order = [0, 1, 2, 3, 4]  # both return (lower_bound, log_px_z, neg_kld_z1, neg_kld_z2, log_pmu2)
+    for k in order:
+        close(got[k], outs[k], what="out%d" % k)
+    assert got[1].requires_grad == (not detach) and got[4].requires_grad == (not detach)
+    sum((o * dev(g)).sum() for o, g in zip(got, gw) if o.requires_grad).backward()
+    for a, r, n in zip(zd, z, "z1_mu z1_lv z2_mu z2_lv mu2".split()):
+        close(a.grad, r.grad, what="d" + n)
+    if detach:
+        assert xmd.grad is None and xld.grad is None and xm.grad is None
+    else:
+        unlay = (lambda t: t.transpose(0, 1)) if tm else (lambda t: t)
+        close(unlay(xmd.grad), xm.grad, what="dx_mu")
+        close(unlay(xld.grad), xl.grad, what="dx_lv")
+
+
+def test_elbo_scalar_nsegs(hb):
+    torch.manual_seed(0)
+    B, T, F, D = 6, 4, 8, 16
+    x, xm, xl = torch.randn(B, T, F), torch.randn(B, T, F), torch.randn(B, T, F) * 0.3
+    z = [torch.randn(B, D) for _ in range(5)]
+    want = R.elbo_terms(x, xm, xl, *z, 17, reference_detach=True)
+    got = hb.elbo(dev(x), dev(xm), dev(xl), *[dev(t) for t in z], 17, (B, T, F, (T * F, F), (T * F, F)), True)
+    for k in range(5):
+        close(got[k], want[k], what="out%d" % k)
+
+
+def test_mu2_gather_with_collisions(hb):
+    torch.manual_seed(0)
+    S, D, B = 12, 16, 40
+    table = torch.randn(S, D, requires_grad=True)
+    idx = torch.randint(0, S, (B,))
+    idx[:8] = 3  # heavy collision on one row
+    g = torch.randn(B, D)
+    R.mu2_gather(table, idx).backward(g)
+    td = dev(table.detach()).requires_grad_(True)
+    out = hb.mu2_gather(td, dev(idx))
+    out.backward(dev(g))
+    close(out, table.detach()[idx], rtol=0, what="gather")
+    close(td.grad, table.grad, what="dtable")
+
+
+@pytest.mark.parametrize("name", ["disc_8x12.npz", "disc_256x4600.npz"])
+def test_disc_lse_golden(hb, golden_dir, name):
+    g = dict(np.load(os.path.join(golden_dir, name)))
+    q = dev(torch.from_numpy(g["q"])).requires_grad_(True)
+    t = dev(torch.from_numpy(g["table"])).requires_grad_(True)
+    idx = dev(torch.from_numpy(g["idx"]))
+    v = hb.disc_lse(q, t, idx)
+    close(v, torch.from_numpy(g["log_qy"]), what="log_qy")
+    v.backward()
+    close(q.grad, torch.from_numpy(g["dq"]), what="dq")
+    close(t.grad, torch.from_numpy(g["dtable"]), what="dtable")
+
+
+@pytest.mark.parametrize("B,S,D,spread", [(3, 5, 4, 1.0), (300, 1000, 32, 1.0), (257, 777, 16, 6.0), (64, 9, 8, 3.0),
+                                          (2048, 4600, 32, 1.0)])
+def test_disc_lse_vs_oracle(hb, B, S, D, spread):
+    torch.manual_seed(B + S)
+    q = (torch.randn(B, D) * spread).requires_grad_(True)
+    t = torch.randn(S, D, requires_grad=True)
+    idx = torch.randint(0, S, (B,))
+    want = R.disc_loss(q, t, idx)
+    (want * 1.7).backward()
+    qd, td = dev(q.detach()).requires_grad_(True), dev(t.detach()).requires_grad_(True)
+    got = hb.disc_lse(qd, td, dev(idx))
+    (got * 1.7).backward()
+    close(got, want, what="log_qy")
+    close(qd.grad, q.grad, what="dq")
+    close(td.grad, t.grad, what="dtable")
+
+
+def test_disc_lse_sharded_partials_combine(hb):
+    """Row-sharded table: per-shard (max, sumexp, target) partials combine to the unsharded value
+    (the multi-GPU exchange of SURVEY 8e, exercised on one GPU)."""
+    torch.manual_seed(5)
+    B, S, D = 130, 1000, 32
+    q, t = torch.randn(B, D) * 2, torch.randn(S, D)
+    idx = torch.randint(0, S, (B,))
+    want = R.disc_loss(q, t, idx)
+    qd, idxd = dev(q), dev(idx)
+    cuts = [0, 250, 251, 700, 1000]
+    ms, ss, tg = [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rmax, rsum, tgt, _, _ = hb.raw_disc_fwd(qd, dev(t[a:b].contiguous()), idxd, row0=a, want_ce=False)
+        ms.append(rmax.cpu()), ss.append(rsum.cpu()), tg.append(tgt.cpu())
+    m = torch.stack(ms).max(0).values
+    s = sum(si * torch.exp(mi - m) for si, mi in zip(ss, ms))
+    ce = (m + torch.log(s) - sum(tg)).mean()
+    close(ce, want, what="sharded CE")
+
+
+def test_adam_matches_torch(hb):
+    torch.manual_seed(0)
+    n = 1000
+    p = torch.randn(n)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.95, 0.999))
+    pd, m, v = dev(p.clone()), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    step = torch.zeros((), dtype=torch.int32).cuda()
+    for k in range(5):
+        g = torch.randn(n)
+        ref.grad = g.clone()
+        opt.step()
+        step += 1
+        hb.adam_step_(pd, dev(g), m, v, step, 1e-3, 0.95, 0.999, 1e-8)
+    close(pd, ref, rtol=1e-5, what="adam p")
