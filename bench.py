@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- ScalableFHVAE training-step throughput on MI355X (contract: see the task statement).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = zero_grad -> forward -> loss_function -> backward -> Adam over one synthetic (B,20,80) batch
+already resident in HBM (train_model.py:446-454).  Workload at N=1: BASELINE.json configs[1]
+(fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 4.6k-row mu2 table).  value = segments/s over all ranks.
+Objective: the intended one (decoder attached, log_qy=-CE): the reference's literal `.detach()`
+objective would skip the whole decoder backward, i.e. less work in the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "pytorch-scalablefhvae_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+
+CONFIGS = {
+    # name: (H, layers, D, S, T, F, default per-GPU batch)
+    "c2": dict(H=256, L=2, D=32, S=4600, T=20, F=80, B=256, desc="fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 4.6k-seq mu2 table"),
+    "c3": dict(H=256, L=2, D=32, S=28000, T=20, F=80, B=2048, desc="same model, 28k-seq mu2 table, batch 2048"),
+    "c4": dict(H=512, L=2, D=32, S=100000, T=20, F=80, B=2048, desc="2x512 LSTM, 100k-seq mu2 table"),
+    "c5": dict(H=256, L=2, D=32, S=1000000, T=40, F=80, B=2048, desc="1M-seq mu2 table, 40-frame segments, fp32"),
+}
+
+
+def lstm_flops_fwd(cfg, B):
+    """Algorithmic forward FLOPs of the three LSTM nets: 2*T*sum 4H(I_l+H) per segment."""
+    H, L, D, T, F = cfg["H"], cfg["L"], cfg["D"], cfg["T"], cfg["F"]
+    per_seg = 0
+    for i0 in (F, F + D, 2 * D):
+        for l in range(L):
+            per_seg += 4 * H * ((i0 if l == 0 else H) + H)
+    return 2 * T * per_seg * B
+
+
+def synth(cfg, B, device, rank):
+    """SURVEY 8d synthetic inputs (seeds 1234/1235/1236, offset by rank)."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(B, cfg["T"], cfg["F"], generator=g)
+    idx = torch.randint(0, cfg["S"], (B,), generator=torch.Generator().manual_seed(1235 + rank))
+    ns = torch.randint(20, 200, (B,), generator=torch.Generator().manual_seed(1236 + rank))
+    return x.to(device), idx.to(device), ns.to(device)
+
+
+def cpu_baseline(cfg, B, budget_s=20.0):
+    """The CPU oracle (oracle/ref_cpu.py, kind 'port': the reference's FHVAE is a stub) timed on
+    this box's host cores on a bounded sample of the same workload: full training steps at the same batch."""
+    from oracle import ref_cpu as R
+
+    H, L, D, S, T, F = (cfg[k] for k in "HLDSTF")
+    torch.manual_seed(0)
+    m = R.FHVAERef(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T)
+    table = torch.randn(S, D, requires_grad=True)
+    opt = torch.optim.Adam(list(m.parameters()) + [table], lr=1e-3, betas=(0.95, 0.999))
+    x = torch.randn(B, T, F)
+    idx = torch.randint(0, S, (B,))
+    ns = torch.randint(20, 200, (B,))
+    e2, e1 = torch.randn(B, D), torch.randn(B, D)
+    R.train_step(m, opt, table, x, idx, ns, e2, e1)  # warm-up
+    t0, n = time.time(), 0
+    while True:
+        R.train_step(m, opt, table, x, idx, ns, e2, e1)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 20:
+            break
+    dt = time.time() - t0
+    return {"value": B * n / dt, "unit": "segments/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full training steps (fwd+loss+bwd+Adam) of the torch-CPU oracle FHVAERef at B=%d, S=%d, fp32" % (n, B, S)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    import hip_binding as hb
+    from fhvae import FHVAE
+    from hip_optim import FusedAdam
+    from train_model import loss_function
+
+    hb.load_library()
+    cfg = CONFIGS[args.config]
+    B = args.batch or cfg["B"]
+    H, L, D, S, T, F = (cfg[k] for k in "HLDSTF")
+    torch.manual_seed(0)
+    model = FHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T, num_seqs=S, reference_compat=False).to(device)
+    with torch.no_grad():
+        model.mu2_table.copy_(torch.randn(S, D, generator=torch.Generator().manual_seed(1)))
+    if world > 1:
+        from dist_shard import DistributedFHVAE
+
+        runner = DistributedFHVAE(model, lr=1e-3, betas=(0.95, 0.999))
+    else:
+        runner = None
+        opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.95, 0.999))
+    x, idx, ns = synth(cfg, B, device, rank)
+
+    def step():
+        if runner is not None:
+            return runner.train_step(x, idx, ns, alpha=10.0)
+        opt.zero_grad()
+        out = model(x, idx, S, ns)
+        loss = loss_function(out[0], out[1], 10.0)
+        loss.backward()
+        opt.step()
+        return loss.detach(), out[0].detach()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, lb = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    elbo = (lb.mean() / T).item()
+    ok = bool(torch.isfinite(loss).item())
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        # instrumented pass: HIP events (torch's current stream == the launch stream) around every C-ABI call
+        hb.OP_TIMER.enable()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        per_op = hb.OP_TIMER.summary()
+        hb.OP_TIMER.disable()
+        lf = lstm_flops_fwd(cfg, B)
+        fwd_ms = per_op.get("fhvae_lstm_seq_fwd", (0, 0.0))[1] / args.steps
+        bwd_ms = per_op.get("fhvae_lstm_seq_bwd", (0, 0.0))[1] / args.steps
+        # dominant op: the LSTM sequence kernels (step cells + their weight-gradient GEMMs); bwd = 2x fwd FLOPs
+        ach = (3 * lf) / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
+        peak = 157.3  # TFLOP/s, f32-input MFMA (MI355X_MICROARCH.md: matrix cores)
+        roof = {"bound": "mfma", "kernel": "lstm_seq fwd+bwd (lstm_fwd_step_kernel, lstm_bwd_step_kernel, gemm_kernel)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_op.items())},
+                "launch_ms": {"lstm_seq_fwd_call": fwd_ms / 3.0, "lstm_seq_bwd_call": bwd_ms / 3.0}}
+
+    if rank == 0:
+        rec = {
+            "metric": "segments/sec + ELBO (nats/frame), (B,20,80) fbank", "value": world * B * args.steps / dt,
+            "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "elbo_nats_per_frame": elbo, "loss_finite": ok,
+            "config": {"workload": "%s: %s; per-GPU batch %d, T=%d, F=%d, full train step (fwd+loss+bwd+Adam), "
+                                   "intended objective" % (args.config, cfg["desc"], B, T, F),
+                       "global_batch": world * B, "parallelism": "dp%d+mu2-row-shard" % world if world > 1 else "single"},
+        }
+        if roof:
+            rec["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(cfg, B)
+        print(json.dumps(rec))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

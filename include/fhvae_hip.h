@@ -196,25 +196,25 @@ int fhvae_elbo_bwd(const fhvae_elbo_bwd_desc* d, void* stream);
  *
  * fwd writes per-query partials so that a row-sharded table can be combined across GPUs:
  *   row_max[b], row_sumexp[b] over THIS table's rows, tgt_logit[b] = logit at row idx[b]-row0
- *   (0 if that row is not in [row0, row0+S)); optionally lse[b] = row_max + log(row_sumexp) and, if
- *   ce_mean != NULL, the single-shard scalar ce_mean = mean_b(lse - tgt_logit) (= the reference's
- *   log_qy).
+ *   (0 if that row is not in [row0, row0+S)), and, if ce_mean != NULL, the single-shard scalar
+ *   ce_mean = mean_b( (row_max - tgt_logit) + log(row_sumexp) )  (= the reference's log_qy).
  * ws: workspace of fhvae_disc_lse_ws_bytes(B,S) bytes.
  * ------------------------------------------------------------------------------------------ */
 int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S);
 int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
                        float inv_two_var, float* row_max, float* row_sumexp, float* tgt_logit,
-                       float* lse, float* ce_mean, void* ws, int64_t B, int64_t S, int64_t D,
-                       void* stream);
-/* bwd: given lse[b] (global log-sum-exp of query b over ALL shards) and the scalar scale
- * g = (*g_scale) * g_mul  (= dL/d(ce_mean) / B_total), computes  p[b,s] = exp(logit - lse[b]),  w = g*(p - [s == idx[b]-row0])
+                       float* ce_mean, void* ws, int64_t B, int64_t S, int64_t D, void* stream);
+/* bwd: given the GLOBAL (all shards combined) row_max[b] and row_sumexp[b] and the scalar scale
+ * g = (*g_scale) * g_mul  (= dL/d(ce_mean) / B_total), computes  p[b,s] = exp(logit - row_max[b]) / row_sumexp[b]
+ * (kept as max and sum, not as one log-sum-exp: |max| ~ 1e3 would put its ulp into every p),
+ * w = g*(p - [s == idx[b]-row0])
  *   dq[b,:]     = sum_s w * (-2 c)(q[b]-t[s])      OVERWRITTEN  (partial over this shard's rows)
  *   dtable[s,:] += sum_b w * (+2 c)(q[b]-t[s])     ACCUMULATED
  * g is read from device memory (g_scale, one f32) so the call stays graph-capturable. */
 int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
-                       float inv_two_var, const float* lse, const float* g_scale, float g_mul,
-                       float* dq, float* dtable, void* ws, int64_t B, int64_t S, int64_t D,
-                       void* stream);
+                       float inv_two_var, const float* row_max, const float* row_sumexp,
+                       const float* g_scale, float g_mul, float* dq, float* dtable, void* ws,
+                       int64_t B, int64_t S, int64_t D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Adam (train_model.py:409-411: torch.optim.Adam(lr, betas=(beta_one, beta_two)), eps 1e-8, no

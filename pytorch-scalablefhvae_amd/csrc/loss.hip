@@ -244,8 +244,7 @@ __global__ __launch_bounds__(256) void disc_combine_kernel(const float* __restri
                                                            const int64_t* __restrict__ idx, int64_t row0, float c,
                                                            const float2* __restrict__ part, int nchunks,
                                                            float* __restrict__ row_max, float* __restrict__ row_sum,
-                                                           float* __restrict__ tgt, float* __restrict__ lse, int B,
-                                                           int S) {
+                                                           float* __restrict__ tgt, int B, int S) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   float m = -INFINITY, sum = 0.f;
@@ -260,7 +259,6 @@ __global__ __launch_bounds__(256) void disc_combine_kernel(const float* __restri
   }
   row_max[b] = m;
   row_sum[b] = sum;
-  if (lse) lse[b] = m + logf(sum);
   const int64_t s = idx[b] - row0;
   float t = 0.f;
   if (s >= 0 && s < S) {
@@ -280,7 +278,7 @@ __global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ 
                                                       const float* __restrict__ tgt, float* __restrict__ out, int B) {
   __shared__ float red[4];
   float s = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) s += row_max[b] + logf(row_sum[b]) - tgt[b];
+  for (int b = threadIdx.x; b < B; b += 256) s += (row_max[b] - tgt[b]) + logf(row_sum[b]);  // exact 0 + log s when the target row is the max
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -291,8 +289,9 @@ __global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ 
 template <int D>
 __global__ __launch_bounds__(256) void disc_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ table,
                                                           const int64_t* __restrict__ idx, int64_t row0, float c,
-                                                          const float* __restrict__ lse, const float* __restrict__ gsc,
-                                                          float gmul, float* __restrict__ dq, int B, int S, int chunk) {
+                                                          const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                          const float* __restrict__ gsc, float gmul,
+                                                          float* __restrict__ dq, int B, int S, int chunk) {
   __shared__ float tr[256][D + 1];
   const int b = blockIdx.x * 256 + threadIdx.x;
   const int bb = b < B ? b : B - 1;
@@ -303,21 +302,30 @@ __global__ __launch_bounds__(256) void disc_bwd_dq_kernel(const float* __restric
     V[d] = 0.f;
   }
   const float g = *gsc * gmul;
-  const float ls = lse[bb];
+  // p = exp(logit - max) / sumexp: the max is one of the logits exactly, so the subtraction is exact for
+  // the rows that matter (an lse = max + log(sum) would carry the ulp of |max| ~ 1e3 into every p)
+  const float mb = rmax[bb], inv_s = 1.f / rsum[bb];
   const int64_t tg = idx[bb] - row0;
-  float W = 0.f;
   const int s0 = blockIdx.y * chunk, s1 = min(S, s0 + chunk);
   for (int s = s0; s < s1; ++s) {
     const float* trow = table + (int64_t)s * D;
-    const float lg = -c * sqdist<D>(qr, trow);
-    float w = g * (__expf(lg - ls) - (s == tg ? 1.f : 0.f));
-    W += w;
+    float df[D];
+    float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) V[d] = fmaf(w, trow[d], V[d]);
+    for (int d = 0; d < D; d += 2) {
+      df[d] = qr[d] - trow[d];
+      df[d + 1] = qr[d + 1] - trow[d + 1];
+      a0 = fmaf(df[d], df[d], a0);
+      a1 = fmaf(df[d + 1], df[d + 1], a1);
+    }
+    const float lg = -c * (a0 + a1);
+    const float w = g * (__expf(lg - mb) * inv_s - (s == tg ? 1.f : 0.f));
+#pragma unroll
+    for (int d = 0; d < D; ++d) V[d] = fmaf(w, df[d], V[d]);
   }
   // transpose through LDS so the atomics go out as contiguous rows (MI355X_MICROARCH.md, float atomics)
 #pragma unroll
-  for (int d = 0; d < D; ++d) tr[threadIdx.x][d] = -2.f * c * (qr[d] * W - V[d]);
+  for (int d = 0; d < D; ++d) tr[threadIdx.x][d] = -2.f * c * V[d];
   __syncthreads();
   for (int i = threadIdx.x; i < 256 * D; i += 256) {
     const int r = i / D, d = i % D;
@@ -331,8 +339,9 @@ __global__ __launch_bounds__(256) void disc_bwd_dq_kernel(const float* __restric
 template <int D>
 __global__ __launch_bounds__(256) void disc_bwd_dt_kernel(const float* __restrict__ q, const float* __restrict__ table,
                                                           const int64_t* __restrict__ idx, int64_t row0, float c,
-                                                          const float* __restrict__ lse, const float* __restrict__ gsc,
-                                                          float gmul, float* __restrict__ dtable, int B, int S, int bchunk) {
+                                                          const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                          const float* __restrict__ gsc, float gmul,
+                                                          float* __restrict__ dtable, int B, int S, int bchunk) {
   __shared__ float tr[256][D + 1];
   const int s = blockIdx.x * 256 + threadIdx.x;
   const int ss = s < S ? s : S - 1;
@@ -343,25 +352,25 @@ __global__ __launch_bounds__(256) void disc_bwd_dt_kernel(const float* __restric
     U[d] = 0.f;
   }
   const float g = *gsc * gmul;
-  float W = 0.f;
   const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
   for (int b = b0; b < b1; ++b) {
     const float* qrow = q + (int64_t)b * D;
+    float df[D];
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int d = 0; d < D; d += 2) {
-      const float d0 = qrow[d] - t[d], d1 = qrow[d + 1] - t[d + 1];
-      a0 = fmaf(d0, d0, a0);
-      a1 = fmaf(d1, d1, a1);
+      df[d] = qrow[d] - t[d];
+      df[d + 1] = qrow[d + 1] - t[d + 1];
+      a0 = fmaf(df[d], df[d], a0);
+      a1 = fmaf(df[d + 1], df[d + 1], a1);
     }
     const float lg = -c * (a0 + a1);
-    const float w = g * (__expf(lg - lse[b]) - ((int64_t)s == idx[b] - row0 ? 1.f : 0.f));
-    W += w;
+    const float w = g * (__expf(lg - rmax[b]) / rsum[b] - ((int64_t)s == idx[b] - row0 ? 1.f : 0.f));
 #pragma unroll
-    for (int d = 0; d < D; ++d) U[d] = fmaf(w, qrow[d], U[d]);
+    for (int d = 0; d < D; ++d) U[d] = fmaf(w, df[d], U[d]);
   }
 #pragma unroll
-  for (int d = 0; d < D; ++d) tr[threadIdx.x][d] = 2.f * c * (U[d] - t[d] * W);
+  for (int d = 0; d < D; ++d) tr[threadIdx.x][d] = 2.f * c * U[d];
   __syncthreads();
   for (int i = threadIdx.x; i < 256 * D; i += 256) {
     const int r = i / D, d = i % D;
@@ -528,8 +537,8 @@ extern "C" int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S) {
   }
 
 extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float inv_two_var,
-                                  float* row_max, float* row_sumexp, float* tgt_logit, float* lse, float* ce_mean, void* ws,
-                                  int64_t B, int64_t S, int64_t D, void* stream) {
+                                  float* row_max, float* row_sumexp, float* tgt_logit, float* ce_mean, void* ws, int64_t B,
+                                  int64_t S, int64_t D, void* stream) {
   FH_CHECK_PTR(q);
   FH_CHECK_PTR(table);
   FH_CHECK_PTR(idx);
@@ -550,8 +559,7 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
   int e = fh_launch_status();
   if (e) return e;
   DISC_DISPATCH(D, hipLaunchKernelGGL((disc_combine_kernel<DD>), dim3((unsigned)p.btiles), dim3(256), 0, st, q, table, idx,
-                                      row0, inv_two_var, part, p.nchunks, row_max, row_sumexp, tgt_logit, lse, (int)B,
-                                      (int)S));
+                                      row0, inv_two_var, part, p.nchunks, row_max, row_sumexp, tgt_logit, (int)B, (int)S));
   e = fh_launch_status();
   if (e) return e;
   if (ce_mean) {
@@ -562,12 +570,13 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
 }
 
 extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float inv_two_var,
-                                  const float* lse, const float* g_scale, float g_mul, float* dq, float* dtable, void* ws,
-                                  int64_t B, int64_t S, int64_t D, void* stream) {
+                                  const float* row_max, const float* row_sumexp, const float* g_scale, float g_mul,
+                                  float* dq, float* dtable, void* ws, int64_t B, int64_t S, int64_t D, void* stream) {
   FH_CHECK_PTR(q);
   FH_CHECK_PTR(table);
   FH_CHECK_PTR(idx);
-  FH_CHECK_PTR(lse);
+  FH_CHECK_PTR(row_max);
+  FH_CHECK_PTR(row_sumexp);
   FH_CHECK_PTR(g_scale);
   FH_CHECK_POS(B);
   FH_CHECK_POS(S);
@@ -581,7 +590,7 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
     DiscPlan p = disc_plan(B, S);
     dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
     DISC_DISPATCH(D, hipLaunchKernelGGL((disc_bwd_dq_kernel<DD>), grid, dim3(256), 0, st, q, table, idx, row0, inv_two_var,
-                                        lse, g_scale, g_mul, dq, (int)B, (int)S, p.chunk));
+                                        row_max, row_sumexp, g_scale, g_mul, dq, (int)B, (int)S, p.chunk));
     int e = fh_launch_status();
     if (e) return e;
   }
@@ -589,7 +598,7 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
     DiscPlan p = disc_plan(S, B);  // roles swapped: threads = rows, chunks over queries
     dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
     DISC_DISPATCH(D, hipLaunchKernelGGL((disc_bwd_dt_kernel<DD>), grid, dim3(256), 0, st, q, table, idx, row0, inv_two_var,
-                                        lse, g_scale, g_mul, dtable, (int)B, (int)S, p.chunk));
+                                        row_max, row_sumexp, g_scale, g_mul, dtable, (int)B, (int)S, p.chunk));
     int e = fh_launch_status();
     if (e) return e;
   }

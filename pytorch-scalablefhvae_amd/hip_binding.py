@@ -87,8 +87,8 @@ SIGNATURES = {
     "fhvae_elbo_fwd": (C.c_int, [C.POINTER(ElboDesc), _vp]),
     "fhvae_elbo_bwd": (C.c_int, [C.POINTER(ElboBwdDesc), _vp]),
     "fhvae_disc_lse_ws_bytes": (_i64, [_i64, _i64]),
-    "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
-    "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "fhvae_to_time_major": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
     "fhvae_cast_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
@@ -116,6 +116,56 @@ def load_library(path: str = LIB_PATH):
         raise RuntimeError("libfhvae_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+class _OpTimer:
+    """Optional HIP-event timing of every C-ABI call (bench.py's roofline leg).  Events are recorded on
+    torch's current stream, which is the stream the kernels are enqueued on."""
+
+    def __init__(self):
+        self.on = False
+        self.pairs = []
+
+    def enable(self):
+        self.on, self.pairs = True, []
+
+    def disable(self):
+        self.on = False
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, name, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.pairs.append((name, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.pairs:
+            n, t = out.get(name, (0, 0.0))
+            out[name] = (n + 1, t + e0.elapsed_time(e1))
+        return out
+
+
+OP_TIMER = _OpTimer()
+
+
+class _Timed:
+    """`with _Timed("fhvae_xxx"):` around a library call."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.e0 = OP_TIMER.start() if OP_TIMER.on else None
+
+    def __exit__(self, *exc):
+        if self.e0 is not None:
+            OP_TIMER.stop(self.name, self.e0)
 
 
 def _check(code: int, what: str):
@@ -157,8 +207,9 @@ def raw_linear_fwd(x, w, b, relu=False):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    _check(lib.fhvae_linear_fwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(b), _p(y), N, None, M, K, N, int(relu), F32,
-                                _stream()), "fhvae_linear_fwd")
+    with _Timed("fhvae_linear_fwd"):
+        _check(lib.fhvae_linear_fwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(b), _p(y), N, None, M, K, N, int(relu), F32,
+                                    _stream()), "fhvae_linear_fwd")
     return y
 
 
@@ -172,9 +223,10 @@ def raw_linear_bwd(x, w, y, dy, relu, need_dx=True, need_dw=True, need_db=True, 
     dx = dx_out if acc else (torch.empty(M, K, device=dev, dtype=torch.float32) if need_dx else None)
     dw = torch.zeros(N, K, device=dev, dtype=torch.float32) if need_dw else None
     db = torch.zeros(N, device=dev, dtype=torch.float32) if need_db else None
-    _check(lib.fhvae_linear_bwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(y), N if y is not None else 0, _p(dy),
-                                dy.stride(0), _p(masked), _p(dx), K, _p(dw), K, _p(db), M, K, N, int(relu), int(acc),
-                                _stream()), "fhvae_linear_bwd")
+    with _Timed("fhvae_linear_bwd"):
+        _check(lib.fhvae_linear_bwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(y), N if y is not None else 0, _p(dy),
+                                    dy.stride(0), _p(masked), _p(dx), K, _p(dw), K, _p(db), M, K, N, int(relu), int(acc),
+                                    _stream()), "fhvae_linear_bwd")
     return dx, dw, db
 
 
@@ -223,8 +275,9 @@ class _GaussHead(torch.autograd.Function):
             smp = torch.empty_like(mu)
         else:
             smp = None
-        _check(lib.fhvae_gauss_head_reparam_fwd(_p(h), h.stride(0), _p(w_mu), _p(w_lv), _p(b_mu), _p(b_lv), _p(eps), _p(mu),
-                                                _p(lv), _p(smp), M, K, D, F32, _stream()), "fhvae_gauss_head_reparam_fwd")
+        with _Timed("fhvae_gauss_head_reparam_fwd"):
+            _check(lib.fhvae_gauss_head_reparam_fwd(_p(h), h.stride(0), _p(w_mu), _p(w_lv), _p(b_mu), _p(b_lv), _p(eps), _p(mu),
+                                                    _p(lv), _p(smp), M, K, D, F32, _stream()), "fhvae_gauss_head_reparam_fwd")
         ctx.save_for_backward(h, w_mu, w_lv, eps, lv)
         if smp is None:
             smp = mu.new_zeros(())  # placeholder output, never differentiable
@@ -243,8 +296,9 @@ class _GaussHead(torch.autograd.Function):
         d_mu = _f32c(d_mu) if d_mu is not None else None
         d_lv = _f32c(d_lv) if d_lv is not None else None
         d_s = _f32c(d_s) if d_s is not None else None
-        _check(lib.fhvae_gauss_reparam_bwd(_p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), _p(g_mu), _p(g_lv), M * D, _stream()),
-               "fhvae_gauss_reparam_bwd")
+        with _Timed("fhvae_gauss_reparam_bwd"):
+            _check(lib.fhvae_gauss_reparam_bwd(_p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), _p(g_mu), _p(g_lv), M * D, _stream()),
+                   "fhvae_gauss_reparam_bwd")
         need_dh = ctx.needs_input_grad[0]
         dh, dw_mu, db_mu = raw_linear_bwd(h, w_mu, None, g_mu, False, need_dx=need_dh)
         _, dw_lv, db_lv = raw_linear_bwd(h, w_lv, None, g_lv, False, need_dx=need_dh, dx_out=dh if need_dh else None)
@@ -263,7 +317,8 @@ def to_time_major(x: torch.Tensor) -> torch.Tensor:
     x = _f32c(x.detach())
     B, T, F_ = x.shape
     out = torch.empty(T, B, F_, device=x.device, dtype=torch.float32)
-    _check(lib.fhvae_to_time_major(_p(x), _p(out), None, B, T, F_, F32, _stream()), "fhvae_to_time_major")
+    with _Timed("fhvae_to_time_major"):
+        _check(lib.fhvae_to_time_major(_p(x), _p(out), None, B, T, F_, F32, _stream()), "fhvae_to_time_major")
     return out
 
 
@@ -300,7 +355,8 @@ class _LstmSeq(torch.autograd.Function):
         for l in range(L):
             d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_p(params[4 * l + k]) for k in range(4))
         d.hs, d.cs, d.gates, d.hn, d.pre = _p(hs), _p(cs), _p(gates), _p(hn), _p(pre)
-        _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")
+        with _Timed("fhvae_lstm_seq_fwd"):
+            _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")
         ctx.dims = (L, B, T, I, Ic, H)
         ctx.save_for_backward(x_tm, xc, hs, cs, gates, *params)
         return hs[L - 1], hn
@@ -335,7 +391,8 @@ class _LstmSeq(torch.autograd.Function):
         for l in range(L):
             bd.dw_ih[l], bd.dw_hh[l], bd.db_ih[l], bd.db_hh[l] = (_p(grads[4 * l + k]) for k in range(4))
         bd.d_xc = _p(d_xc)
-        _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
+        with _Timed("fhvae_lstm_seq_bwd"):
+            _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
         return (None, d_xc, None, *grads)
 
 
@@ -354,7 +411,8 @@ class _Mu2Gather(torch.autograd.Function):
         S, D = table.shape
         B = idx.shape[0]
         out = torch.empty(B, D, device=table.device, dtype=torch.float32)
-        _check(lib.fhvae_mu2_gather_fwd(_p(table), _p(idx), _p(out), B, S, D, None, _stream()), "fhvae_mu2_gather_fwd")
+        with _Timed("fhvae_mu2_gather_fwd"):
+            _check(lib.fhvae_mu2_gather_fwd(_p(table), _p(idx), _p(out), B, S, D, None, _stream()), "fhvae_mu2_gather_fwd")
         ctx.save_for_backward(idx)
         ctx.shape = (S, D)
         return out
@@ -366,7 +424,8 @@ class _Mu2Gather(torch.autograd.Function):
         S, D = ctx.shape
         dmu2 = _f32c(dmu2)
         dt = torch.zeros(S, D, device=dmu2.device, dtype=torch.float32)
-        _check(lib.fhvae_mu2_gather_bwd(_p(dmu2), _p(idx), _p(dt), idx.shape[0], S, D, _stream()), "fhvae_mu2_gather_bwd")
+        with _Timed("fhvae_mu2_gather_bwd"):
+            _check(lib.fhvae_mu2_gather_bwd(_p(dmu2), _p(idx), _p(dt), idx.shape[0], S, D, _stream()), "fhvae_mu2_gather_bwd")
         return dt, None
 
 
@@ -400,7 +459,8 @@ class _Elbo(torch.autograd.Function):
         d = ElboDesc()
         _fill_elbo_desc(d, ts[0], xs, ts[1], ts[2], xos, *ts[3:], num_segs, B, T, F_)
         d.lower_bound, d.log_px_z, d.neg_kld_z1, d.neg_kld_z2, d.log_pmu2 = (_p(o) for o in outs)
-        _check(lib.fhvae_elbo_fwd(C.byref(d), _stream()), "fhvae_elbo_fwd")
+        with _Timed("fhvae_elbo_fwd"):
+            _check(lib.fhvae_elbo_fwd(C.byref(d), _stream()), "fhvae_elbo_fwd")
         ctx.layout, ctx.detach = layout, bool(reference_detach)
         ctx.nsegs = num_segs
         ctx.save_for_backward(*ts)
@@ -426,11 +486,14 @@ class _Elbo(torch.autograd.Function):
         dz = [torch.empty_like(t) for t in ts[3:8]]
         bd.d_x_mu, bd.d_x_lv = _p(d_xmu), _p(d_xlv)
         bd.d_z1_mu, bd.d_z1_lv, bd.d_z2_mu, bd.d_z2_lv, bd.d_mu2 = (_p(t) for t in dz)
-        _check(lib.fhvae_elbo_bwd(C.byref(bd), _stream()), "fhvae_elbo_bwd")
+        with _Timed("fhvae_elbo_bwd"):
+            _check(lib.fhvae_elbo_bwd(C.byref(bd), _stream()), "fhvae_elbo_bwd")
         return (None, d_xmu, d_xlv, *dz, None, None, None)
 
 
 def elbo(x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2, num_segs, layout, reference_detach):
+    if reference_detach:  # simple_fhvae.py:114: the decoder outputs are detached -> its graph is not reached
+        x_mu, x_lv = x_mu.detach(), x_lv.detach()
     return _Elbo.apply(x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2, num_segs, layout, bool(reference_detach))
 
 
@@ -440,21 +503,23 @@ def raw_disc_fwd(q, table, idx, row0=0, want_ce=True):
     S = table.shape[0]
     dev = q.device
     ws = torch.empty(max(int(lib.fhvae_disc_lse_ws_bytes(B, S)), 8), device=dev, dtype=torch.uint8)
-    rmax, rsum, tgt, lse = (torch.empty(B, device=dev, dtype=torch.float32) for _ in range(4))
+    rmax, rsum, tgt = (torch.empty(B, device=dev, dtype=torch.float32) for _ in range(3))
     ce = torch.empty((), device=dev, dtype=torch.float32) if want_ce else None
-    _check(lib.fhvae_disc_lse_fwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(tgt), _p(lse), _p(ce),
-                                  _p(ws), B, S, D, _stream()), "fhvae_disc_lse_fwd")
-    return rmax, rsum, tgt, lse, ce
+    with _Timed("fhvae_disc_lse_fwd"):
+        _check(lib.fhvae_disc_lse_fwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(tgt), _p(ce), _p(ws),
+                                      B, S, D, _stream()), "fhvae_disc_lse_fwd")
+    return rmax, rsum, tgt, ce
 
 
-def raw_disc_bwd(q, table, idx, lse, g_scale, g_mul, row0=0, need_dq=True, need_dt=True):
+def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True, need_dt=True):
     lib = load_library()
     B, D = q.shape
     S = table.shape[0]
     dq = torch.empty(B, D, device=q.device, dtype=torch.float32) if need_dq else None
     dt = torch.zeros(S, D, device=q.device, dtype=torch.float32) if need_dt else None
-    _check(lib.fhvae_disc_lse_bwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(lse), _p(g_scale), float(g_mul), _p(dq),
-                                  _p(dt), None, B, S, D, _stream()), "fhvae_disc_lse_bwd")
+    with _Timed("fhvae_disc_lse_bwd"):
+        _check(lib.fhvae_disc_lse_bwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(g_scale), float(g_mul),
+                                      _p(dq), _p(dt), None, B, S, D, _stream()), "fhvae_disc_lse_bwd")
     return dq, dt
 
 
@@ -466,15 +531,15 @@ class _DiscLse(torch.autograd.Function):
     def forward(ctx, q, table, idx):
         _need_gpu(q, table, idx)
         q, table = _f32c(q), _f32c(table)
-        _, _, _, lse, ce = raw_disc_fwd(q, table, idx)
-        ctx.save_for_backward(q, table, idx, lse)
+        rmax, rsum, _, ce = raw_disc_fwd(q, table, idx)
+        ctx.save_for_backward(q, table, idx, rmax, rsum)
         return ce
 
     @staticmethod
     def backward(ctx, g):
-        q, table, idx, lse = ctx.saved_tensors
+        q, table, idx, rmax, rsum = ctx.saved_tensors
         g = _f32c(g).reshape(1)
-        dq, dt = raw_disc_bwd(q, table, idx, lse, g, 1.0 / q.shape[0], need_dq=ctx.needs_input_grad[0],
+        dq, dt = raw_disc_bwd(q, table, idx, rmax, rsum, g, 1.0 / q.shape[0], need_dq=ctx.needs_input_grad[0],
                               need_dt=ctx.needs_input_grad[1])
         return dq, dt, None
 
@@ -488,5 +553,6 @@ def adam_step_(p, g, m, v, step_dev, lr, beta1, beta2, eps, grad_scale=1.0, p_lp
     lib = load_library()
     _need_gpu(p, g, m, v, step_dev)
     n = p.numel()
-    _check(lib.fhvae_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, lr, beta1, beta2, eps, grad_scale, _p(step_dev),
-                               _stream()), "fhvae_adam_step")
+    with _Timed("fhvae_adam_step"):
+        _check(lib.fhvae_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, lr, beta1, beta2, eps, grad_scale, _p(step_dev),
+                                   _stream()), "fhvae_adam_step")

@@ -1,0 +1,70 @@
+"""Adam on the HIP kernel (fhvae_adam_step) with the reference's hyper-parameters
+(train_model.py:409-411: Adam(lr, betas=(beta_one, beta_two)), eps 1e-8, no weight decay).
+
+Parameters are packed into ONE flat f32 arena (parameters become views of it) so that the optimizer
+is a single elementwise launch per step and data-parallel gradient reduction is one (bucketed)
+collective over the flat gradient arena.  The step counter lives on the device so a captured
+hipGraph advances the bias correction on replay.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+
+import hip_binding as hb
+
+
+class FlatArena:
+    """Packs tensors into one flat f32 buffer; `views[i]` aliases the i-th tensor's storage."""
+
+    def __init__(self, tensors: List[torch.Tensor], align: int = 64):
+        dev = tensors[0].device
+        offs, n = [], 0
+        for t in tensors:
+            offs.append(n)
+            n += (t.numel() + align - 1) // align * align
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.offsets, self.numel = offs, n
+        self.views = [self.flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, tensors)]
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.95, 0.999), eps=1e-8, grad_scale=1.0):
+        params = [p for p in params if p.requires_grad]
+        if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            raise RuntimeError("FusedAdam needs float32 parameters on a MI355X device")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.grad_scale = float(grad_scale)
+        self._params = params
+        with torch.no_grad():
+            self.p_arena = FlatArena(params)
+            self.g_arena = FlatArena(params)
+            for p, pv, gv in zip(params, self.p_arena.views, self.g_arena.views):
+                pv.copy_(p.data)
+                p.data = pv          # the parameter now lives in the arena
+                p.grad = gv          # gradients accumulate straight into the flat gradient arena
+        self.m = torch.zeros_like(self.p_arena.flat)
+        self.v = torch.zeros_like(self.p_arena.flat)
+        self.step_dev = torch.zeros((), device=params[0].device, dtype=torch.int32)
+
+    def zero_grad(self, set_to_none: bool = False):
+        # keep the arena views attached (set_to_none would detach them); one memset for everything
+        self.g_arena.flat.zero_()
+        for p, gv in zip(self._params, self.g_arena.views):
+            if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                p.grad = gv
+
+    def flat_grad(self) -> torch.Tensor:
+        return self.g_arena.flat
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for p, gv in zip(self._params, self.g_arena.views):
+            if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)  # a gradient produced outside the arena (first backward after set_to_none)
+                p.grad = gv
+        g = self.param_groups[0]
+        self.step_dev += 1
+        hb.adam_step_(self.p_arena.flat, self.g_arena.flat, self.m, self.v, self.step_dev, g["lr"], g["betas"][0],
+                      g["betas"][1], g["eps"], self.grad_scale)
