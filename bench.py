@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
+                    help="MFMA operand type of the LSTM nets (configs[1] is quoted in bf16; f32 = exact-f32 parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -112,7 +114,8 @@ def main():
     B = args.batch or cfg["B"]
     H, L, D, S, T, F = (cfg[k] for k in "HLDSTF")
     torch.manual_seed(0)
-    model = FHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T, num_seqs=S, reference_compat=False).to(device)
+    model = FHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T, num_seqs=S, reference_compat=False,
+                  compute_dtype=args.dtype).to(device)
     with torch.no_grad():
         model.mu2_table.copy_(torch.randn(S, D, generator=torch.Generator().manual_seed(1)))
     if world > 1:
@@ -172,7 +175,8 @@ def main():
         bwd_ms = per_op.get("fhvae_lstm_seq_bwd", (0, 0.0))[1] / args.steps
         # dominant op: the LSTM sequence kernels (step cells + their weight-gradient GEMMs); bwd = 2x fwd FLOPs
         ach = (3 * lf) / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
-        peak = 157.3  # TFLOP/s, f32-input MFMA (MI355X_MICROARCH.md: matrix cores)
+        # dense MFMA peaks (MI355X_MICROARCH.md, matrix cores): bf16 ~2500 TFLOP/s, f32-input 157.3 TFLOP/s
+        peak = 2500.0 if args.dtype == "bf16" else 157.3
         roof = {"bound": "mfma", "kernel": "lstm_seq fwd+bwd (lstm_fwd_step_kernel, lstm_bwd_step_kernel, gemm_kernel)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                 "ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_op.items())},
@@ -183,7 +187,7 @@ def main():
             "metric": "segments/sec + ELBO (nats/frame), (B,20,80) fbank", "value": world * B * args.steps / dt,
             "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "elbo_nats_per_frame": elbo, "loss_finite": ok,
+            "dtype": args.dtype, "data": "synthetic", "elbo_nats_per_frame": elbo, "loss_finite": ok,
             "config": {"workload": "%s: %s; per-GPU batch %d, T=%d, F=%d, full train step (fwd+loss+bwd+Adam), "
                                    "intended objective" % (args.config, cfg["desc"], B, T, F),
                        "global_batch": world * B, "parallelism": "dp%d+mu2-row-shard" % world if world > 1 else "single"},

@@ -93,27 +93,29 @@ int fhvae_gauss_reparam_bwd(const float* d_mu, const float* d_logvar, const floa
  * [4H, I+Ic].  Layers l >= 1 take h^{l-1}_t (H cols).  All layers share H.
  * ------------------------------------------------------------------------------------------ */
 typedef struct fhvae_lstm_desc {
-  int32_t dtype;  /* FHVAE_F32 | FHVAE_BF16: type of x, xc, w_*, hs */
+  int32_t dtype;  /* FHVAE_F32 | FHVAE_BF16: MFMA operand type used inside */
   int32_t L;      /* layers, 1..FHVAE_MAX_LAYERS */
   int64_t B, T, I, Ic, H;
-  const void* x;   /* (T,B,I) time-major, operand dtype */
-  const void* xc;  /* (B,Ic) operand dtype */
-  const void* w_ih[FHVAE_MAX_LAYERS]; /* [4H, I+Ic] (l=0) / [4H, H], operand dtype */
-  const void* w_hh[FHVAE_MAX_LAYERS]; /* [4H, H] */
-  const float* b_ih[FHVAE_MAX_LAYERS]; /* [4H] f32 */
+  /* inputs and parameters are ALWAYS f32 (master copies) */
+  const float* x;   /* (T,B,I) time-major */
+  const float* xc;  /* (B,Ic) */
+  const float* w_ih[FHVAE_MAX_LAYERS]; /* [4H, I+Ic] (l=0) / [4H, H] */
+  const float* w_hh[FHVAE_MAX_LAYERS]; /* [4H, H] */
+  const float* b_ih[FHVAE_MAX_LAYERS]; /* [4H] */
   const float* b_hh[FHVAE_MAX_LAYERS];
-  /* transposed weight copies, needed by the BF16 backward only (operand dtype):
-   * w_ih_t[l] = w_ih[l]^T ([H,4H], l >= 1), w_hh_t[l] = w_hh[l]^T ([H,4H]) */
-  const void* w_ih_t[FHVAE_MAX_LAYERS];
-  const void* w_hh_t[FHVAE_MAX_LAYERS];
   /* forward outputs, saved for backward */
-  void* hs;      /* (L,T,B,H) operand dtype: h^l_t */
+  void* hs;      /* (L,T,B,H) in the operand dtype (f32 or bf16): h^l_t */
   float* cs;     /* (L,T,B,H) f32: c^l_t */
   float* gates;  /* (L,T,B,4H) f32: activated i,f,g,o (column blocks of H) */
   float* hn;     /* (B, L*H) f32: final hidden state of every layer, concatenated (may be NULL) */
+  float* hs_top_f32; /* (T,B,H) f32 copy of the top layer's h_t (BF16 mode, may be NULL; in F32 mode
+                        the top layer is hs + (L-1)*T*B*H and this must be NULL) */
   float* pre;    /* workspace (T,B,4H) f32 (I > 0) or (B,4H) (I == 0): layer-0 input projection */
+  void* lp;      /* BF16 mode: workspace of fhvae_lstm_lp_bytes() bytes; the forward fills it with bf16
+                    copies of x, xc, the weights and the transposed weights, the backward reuses it */
 } fhvae_lstm_desc;
 
+int64_t fhvae_lstm_lp_bytes(const fhvae_lstm_desc* d);
 int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream);
 
 typedef struct fhvae_lstm_bwd_desc {
@@ -124,16 +126,12 @@ typedef struct fhvae_lstm_bwd_desc {
   void* dgates;   /* (L,T,B,4H) operand dtype: gradient w.r.t. pre-activation gates */
   float* dgsum;   /* (B,4H) f32: sum_t dgates of layer 0 (required iff Ic > 0) */
   float* dc;      /* (L,B,H) f32: running cell-state gradient */
-  /* outputs (ACCUMULATED: += ; any may be NULL) */
-  float* dw_ih[FHVAE_MAX_LAYERS]; /* f32, same shapes as w_ih (master-gradient precision) */
+  /* outputs, f32 (ACCUMULATED: += ; any may be NULL) */
+  float* dw_ih[FHVAE_MAX_LAYERS];
   float* dw_hh[FHVAE_MAX_LAYERS];
   float* db_ih[FHVAE_MAX_LAYERS];
   float* db_hh[FHVAE_MAX_LAYERS];
   float* d_xc;    /* (B,Ic) f32, OVERWRITTEN (may be NULL) */
-  /* f32 copies of the layer inputs for the weight-gradient contraction (BF16 mode only; in F32
-   * mode they alias f.x / f.xc / f.hs): */
-  const float* x_f32;   /* (T,B,I) */
-  const float* xc_f32;  /* (B,Ic) */
 } fhvae_lstm_bwd_desc;
 
 int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* d, void* stream);

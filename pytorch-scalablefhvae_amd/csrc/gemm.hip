@@ -9,13 +9,13 @@ namespace fh {
 // ---------------------------------------------------------------------------------------------
 // generic GEMM kernel: C = epi(sum_seg A.B^T)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int CH>
 __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
-  using TL = Tile<T, BM, BN, WM, WN>;
+  using TL = Tile<T, BM, BN, WM, WN, CH>;
   constexpr int TM = TL::TM, TN = TL::TN;
   __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int nkb = num_kblocks<T>(p.seg);
+  const int nkb = num_kblocks<T, CH>(p.seg);
   // split-K: contiguous ranges of K-blocks per z-slice
   const int per = (nkb + p.splitk - 1) / p.splitk;
   const int it0 = blockIdx.z * per;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   f32x4 acc[TM][TN];
   zero_acc(acc);
   RowIdent arm{p.M}, brm{p.N};
-  mainloop<T, BM, BN, WM, WN>(acc, p.seg, m0, p.M, n0, p.N, arm, brm, it0, it1, smem);
+  mainloop<T, BM, BN, WM, WN, CH>(acc, p.seg, m0, p.M, n0, p.N, arm, brm, it0, it1, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -66,12 +66,19 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0) return FHVAE_ERR_SHAPE;
   if (p.splitk < 1) p.splitk = 1;
   dim3 grid((unsigned)fh_cdiv(p.N, 64), (unsigned)fh_cdiv(p.M, 64), (unsigned)p.splitk);
+  const int kmax = p.seg[0].K > p.seg[1].K ? p.seg[0].K : p.seg[1].K;
   if (dtype == FHVAE_F32) {
-    hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 2, 2>), grid, dim3(kThreads), 0, st, p);
+    if (kmax <= 64)  // short contraction: 128-byte panels
+      hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 2, 2, 8>), grid, dim3(kThreads), 0, st, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 2, 2, 32>), grid, dim3(kThreads), 0, st, p);
   } else if (dtype == FHVAE_BF16) {
     for (int s = 0; s < 2; ++s)
-      if (p.seg[s].K > 0 && (!p.seg[s].a_kc || !p.seg[s].b_kc)) return FHVAE_ERR_DTYPE;  // bf16: KC images only
-    hipLaunchKernelGGL((gemm_kernel<u16, 64, 64, 2, 2>), grid, dim3(kThreads), 0, st, p);
+      if (p.seg[s].K > 0 && (p.seg[s].a_kc != p.seg[s].b_kc)) return FHVAE_ERR_DTYPE;  // bf16: KC/KC or KM/KM
+    if (kmax <= 128)
+      hipLaunchKernelGGL((gemm_kernel<u16, 64, 64, 2, 2, 8>), grid, dim3(kThreads), 0, st, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<u16, 64, 64, 2, 2, 32>), grid, dim3(kThreads), 0, st, p);
   } else {
     return FHVAE_ERR_DTYPE;
   }
@@ -81,10 +88,10 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
 // heuristic split of the contraction for weight-gradient GEMMs (few output tiles, long K)
 int pick_splitk(int64_t M, int64_t N, int64_t K) {
   int64_t tiles = fh_cdiv(M, 64) * fh_cdiv(N, 64);
-  int64_t nkb = fh_cdiv(K, 32);
-  if (tiles >= 256 || nkb < 16) return 1;
+  int64_t nkb = fh_cdiv(K, 128);  // panels of the CH = 32 kernels (f32; bf16 panels are 256)
+  if (tiles >= 256 || nkb < 4) return 1;
   int64_t s = fh_cdiv(512, tiles);
-  if (s > nkb / 8) s = nkb / 8;
+  if (s > nkb / 2) s = nkb / 2;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
   return (int)s;
@@ -102,14 +109,20 @@ __global__ void relu_mask_kernel(const float* __restrict__ dy, int64_t lddy, con
 }
 
 // db[n] += sum_m g[m][n] : 64 columns x 4 row lanes per block, rows strided over gridDim.y
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int64_t ldg, float* __restrict__ db,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, int64_t ldg, float* __restrict__ db,
                                                      float* __restrict__ db2, int64_t M, int64_t N) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int64_t n = (int64_t)blockIdx.x * 64 + c;
   float s = 0.f;
   if (n < N)
-    for (int64_t m = (int64_t)blockIdx.y * 4 + rg; m < M; m += (int64_t)gridDim.y * 4) s += g[m * ldg + n];
+    for (int64_t m = (int64_t)blockIdx.y * 4 + rg; m < M; m += (int64_t)gridDim.y * 4) {
+      if constexpr (sizeof(T) == 4)
+        s += g[m * ldg + n];
+      else
+        s += bf2f(g[m * ldg + n]);
+    }
   red[rg][c] = s;
   __syncthreads();
   if (rg == 0 && n < N) {
@@ -119,12 +132,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
   }
 }
 
-int launch_colsum(const float* g, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st) {
+int launch_colsum(const void* g, int dtype, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st) {
   if (!db && !db2) return FHVAE_OK;
   int64_t gy = fh_cdiv(M, 4 * 16);
   if (gy > 64) gy = 64;
   if (gy < 1) gy = 1;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)fh_cdiv(N, 64), (unsigned)gy), dim3(256), 0, st, g, ldg, db, db2, M, N);
+  dim3 grid((unsigned)fh_cdiv(N, 64), (unsigned)gy);
+  if (dtype == FHVAE_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)g, ldg, db, db2, M, N);
+  else
+    hipLaunchKernelGGL(colsum_kernel<u16>, grid, dim3(256), 0, st, (const u16*)g, ldg, db, db2, M, N);
   return fh_launch_status();
 }
 
@@ -230,7 +247,7 @@ extern "C" int fhvae_linear_bwd(const float* x, int64_t ldx, const float* w, int
     if (e) return e;
   }
   if (db) {
-    int e = launch_colsum(g, ldg, db, nullptr, M, N, st);
+    int e = launch_colsum(g, FHVAE_F32, ldg, db, nullptr, M, N, st);
     if (e) return e;
   }
   return FHVAE_OK;

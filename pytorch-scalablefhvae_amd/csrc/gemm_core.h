@@ -7,15 +7,23 @@
 //   * 256-thread workgroup = 4 waves of 64; each wave owns TM x TN tiles of 16x16 accumulators.
 //     f32 operands -> v_mfma_f32_16x16x4_f32 (exact f32, the parity mode);
 //     bf16 operands -> v_mfma_f32_16x16x32_bf16 (f32 accumulate).
-//   * operand tiles are staged global -> registers -> LDS with 16-byte accesses; the next K-block's
-//     global loads are issued before the current block's MFMAs (register prefetch, guide T14).
-//   * "KC" operands (contraction index contiguous in memory) live in LDS as 128-byte rows with the
-//     16-byte chunk index XOR-swizzled by (row & 7) -> the ds_read_b128 fragment reads are
-//     bank-conflict-free (guide T2).  One 16-byte chunk holds 4 consecutive k (f32) and feeds 4
-//     MFMA k-steps with the k order permuted identically for A and B (sum is order-free per step).
-//   * "KM" operands (f32 only: contraction index is the slow dimension, e.g. W in dh = dg . W or both
-//     operands of dW = dg^T . h) are staged untransposed as [32 k][R+4] floats and read with
-//     ds_read_b32; the +4 row pad makes the 4 k-rows of a 32-lane group hit disjoint banks.
+//   * the contraction is consumed in PANELS of CH 16-byte chunks per row (CH = 8: 128-byte rows for
+//     short contractions; CH = 32: 512-byte rows).  The step-cell GEMMs are latency-bound (one
+//     workgroup per CU, everything L2-resident), so a panel issues all its global loads at once
+//     (up to 16 x 16 B per thread in flight) and the next panel's loads are issued before the current
+//     panel's MFMAs (register prefetch, guide T14): the load latency is paid once per panel, not
+//     once per 32 k.
+//   * "KC" operands (contraction index contiguous in memory) live in LDS as rows of CH chunks with the
+//     chunk index XOR-swizzled by the row -> the ds_read_b128 fragment reads are bank-conflict-free
+//     (guide T2).  One 16-byte chunk holds 4 consecutive k (f32: feeds 4 MFMA k-steps with the k order
+//     permuted identically for A and B) or 8 consecutive k (bf16: one lane's share of a 16x16x32).
+//   * "KM" operands (contraction index is the slow dimension: W in dh = dg . W, both operands of
+//     dW = dg^T . h) are staged untransposed.  f32: [k][R+4] floats read with ds_read_b32 (the pad
+//     puts the 4 k-rows of a 32-lane group on disjoint banks).  bf16: [k][R+16] read with
+//     ds_read_b64_tr_b16 (hardware transpose, guide T10): lane group q takes k-rows 4q..4q+3 and
+//     16+4q..16+4q+3 of each 32-k block, so a 32-lane half touches 8 consecutive rows, conflict-free
+//     at the 160-byte row stride.  (That k order differs from the KC order, so in bf16 both operands
+//     of a segment must be KC or both KM.)
 //   * up to two K-segments per tile let a cell consume [h^{l-1}_t ; h^l_{t-1}] without a concat.
 #pragma once
 #include "common.h"
@@ -31,7 +39,7 @@ struct Seg {
   const void* B;
   int64_t ldb;
   int b_kc;  // 1: B(n,k) = B[n*ldb + k]   0: B(n,k) = B[k*ldb + n]
-  int K;     // contraction length (0 = segment unused)
+  int K;       // contraction length (0 = segment unused)
   int a_rmod;  // > 0: A row m is read from physical row (m % a_rmod) (time-constant inputs broadcast over t)
 };
 
@@ -39,13 +47,13 @@ template <typename T>
 struct Op;
 template <>
 struct Op<float> {
-  static constexpr int EPC = 4;   // elements per 16-byte chunk
-  static constexpr int BK = 32;   // k per staged block (128-byte KC rows)
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+  static constexpr int KMPAD = 4;
 };
 template <>
 struct Op<u16> {  // bf16 bit patterns
   static constexpr int EPC = 8;
-  static constexpr int BK = 64;
+  static constexpr int KMPAD = 16;
 };
 
 struct RowIdent {
@@ -53,10 +61,12 @@ struct RowIdent {
   __device__ __forceinline__ int64_t operator()(int r) const { return r < X ? (int64_t)r : -1; }
 };
 
-// LDS bytes for one operand tile of R rows (max of the KC and KM images)
-template <int R>
+// LDS bytes for one operand tile of R rows and CH chunks (max of the KC and KM images)
+template <typename T, int R, int CH>
 constexpr int tile_bytes() {
-  return 32 * (R + 4) * 4;
+  constexpr int kc = R * CH * 16;
+  constexpr int km = CH * Op<T>::EPC * (R + Op<T>::KMPAD) * (int)sizeof(T);
+  return kc > km ? kc : km;
 }
 
 template <typename T>
@@ -74,19 +84,19 @@ __device__ __forceinline__ uint4 load_elems(const T* p, int nvalid) {
   return r.u;
 }
 
-// global -> registers for one operand tile (R rows x BK k) of K-block starting at k0
-template <typename T, int R, class RowMap>
-__device__ __forceinline__ void load_tile(uint4 (&v)[R * 8 / kThreads], const void* base_, int64_t ld, int kc,
+// global -> registers for one operand panel (R rows x CH chunks) starting at contraction index k0
+template <typename T, int R, int CH, class RowMap>
+__device__ __forceinline__ void load_tile(uint4 (&v)[R * CH / kThreads], const void* base_, int64_t ld, int kc,
                                           bool vec_ok, int x0, int X, int k0, int K, const RowMap& rm, int rmod,
                                           int tid) {
   constexpr int EPC = Op<T>::EPC;
-  constexpr int NCH = R * 8 / kThreads;
+  constexpr int NCH = R * CH / kThreads;
   const T* base = (const T*)base_;
   if (kc) {
 #pragma unroll
     for (int p = 0; p < NCH; ++p) {
       int idx = tid + p * kThreads;
-      int row = idx >> 3, ch = idx & 7;
+      int row = idx / CH, ch = idx % CH;
       int64_t grow = rm(x0 + row);
       if (rmod > 0 && grow >= 0) grow %= rmod;
       int k = k0 + ch * EPC;
@@ -101,16 +111,16 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[R * 8 / kThreads], const vo
       }
     }
   } else {
-    // KM image (f32 only): 32 k-rows of R floats
-    constexpr int CPR = R / 4;  // 16-byte chunks per k-row
+    // KM image: CH*EPC k-rows of R elements
+    constexpr int CPR = R / EPC;  // 16-byte chunks per k-row
 #pragma unroll
     for (int p = 0; p < NCH; ++p) {
       int idx = tid + p * kThreads;
-      int krow = idx / CPR, c4 = idx % CPR;
-      int k = k0 + krow, x = x0 + c4 * 4;
+      int krow = idx / CPR, cx = idx % CPR;
+      int k = k0 + krow, x = x0 + cx * EPC;
       if (k < K && x < X) {
         const T* src = base + (int64_t)k * ld + x;
-        if (vec_ok && x + 4 <= X)
+        if (vec_ok && x + EPC <= X)
           v[p] = *(const uint4*)src;
         else
           v[p] = load_elems<T>(src, X - x);
@@ -121,54 +131,83 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[R * 8 / kThreads], const vo
   }
 }
 
-template <typename T, int R>
-__device__ __forceinline__ void store_tile(const uint4 (&v)[R * 8 / kThreads], char* lds, int kc, int tid) {
-  constexpr int NCH = R * 8 / kThreads;
+template <int CH>
+__device__ __forceinline__ int kc_off(int row, int ch) {
+  constexpr int SW = CH >= 16 ? 15 : CH - 1;
+  return row * (CH * 16) + ((ch ^ (row & SW)) << 4);
+}
+
+template <typename T, int R, int CH>
+__device__ __forceinline__ void store_tile(const uint4 (&v)[R * CH / kThreads], char* lds, int kc, int tid) {
+  constexpr int EPC = Op<T>::EPC;
+  constexpr int NCH = R * CH / kThreads;
   if (kc) {
 #pragma unroll
     for (int p = 0; p < NCH; ++p) {
       int idx = tid + p * kThreads;
-      int row = idx >> 3, ch = idx & 7;
-      *(uint4*)(lds + row * 128 + ((ch ^ (row & 7)) << 4)) = v[p];
+      *(uint4*)(lds + kc_off<CH>(idx / CH, idx % CH)) = v[p];
     }
   } else {
-    constexpr int CPR = R / 4;
+    constexpr int CPR = R / EPC;
+    constexpr int LD = R + Op<T>::KMPAD;
 #pragma unroll
     for (int p = 0; p < NCH; ++p) {
       int idx = tid + p * kThreads;
-      int krow = idx / CPR, c4 = idx % CPR;
-      *(uint4*)(lds + (krow * (R + 4) + c4 * 4) * 4) = v[p];
+      int krow = idx / CPR, cx = idx % CPR;
+      *(uint4*)(lds + (krow * LD + cx * EPC) * (int)sizeof(T)) = v[p];
     }
   }
 }
 
-// 16-byte fragment chunk (4j+q) of LDS row `row` of a KC image
-__device__ __forceinline__ uint4 frag_kc(const char* lds, int row, int j, int q) {
-  return *(const uint4*)(lds + row * 128 + ((((j << 2) | q) ^ (row & 7)) << 4));
-}
-
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int CH>
 struct Tile {
   static constexpr int TM = BM / WM / 16;
   static constexpr int TN = BN / WN / 16;
-  static constexpr int A_BYTES = tile_bytes<BM>();
-  static constexpr int B_BYTES = tile_bytes<BN>();
+  static constexpr int BK = CH * Op<T>::EPC;  // contraction elements per panel
+  static constexpr int A_BYTES = tile_bytes<T, BM, CH>();
+  static constexpr int B_BYTES = tile_bytes<T, BN, CH>();
   static constexpr int SMEM = A_BYTES + B_BYTES;
   static_assert(WM * WN == 4, "4 waves");
   static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "tile/wave shape");
-  static_assert((BM * 8) % kThreads == 0 && (BN * 8) % kThreads == 0, "staging shape");
+  static_assert((BM * CH) % kThreads == 0 && (BN * CH) % kThreads == 0, "staging shape");
+  static_assert(CH == 8 || CH == 16 || CH == 32, "panel width");
 };
 
-// The main loop.  K-blocks of both segments are numbered consecutively; [it_begin, it_end) selects
-// a sub-range (split-K).  smem must hold Tile::SMEM bytes (16-byte aligned).
-template <typename T, int BM, int BN, int WM, int WN, class ARowMap, class BRowMap>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// bf16 KM fragment: 8 k-values of column `col` for lane group q of 32-k block j (two transposed reads)
+template <int LD>
+__device__ __forceinline__ bf16x8 frag_km_bf16(const char* lds, int col0, int j, int lane) {
+  const int q = lane >> 4, i = lane & 15;
+  const int qq = i >> 2, p = i & 3;
+  const int ka = 32 * j + 4 * q;
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const char* a0 = lds + ((ka + qq) * LD + col0 + 4 * p) * 2;
+  const char* a1 = a0 + 16 * LD * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a1));
+  union {
+    struct {
+      s16x4 lo, hi;
+    } s;
+    bf16x8 v;
+  } u;
+  u.s.lo = lo;
+  u.s.hi = hi;
+  return u.v;
+}
+
+// The main loop.  Panels of both segments are numbered consecutively; [it_begin, it_end) selects a
+// sub-range (split-K).  smem must hold Tile::SMEM bytes (16-byte aligned).
+template <typename T, int BM, int BN, int WM, int WN, int CH, class ARowMap, class BRowMap>
 __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const Seg (&segs)[2], int m0, int M,
                                          int n0, int N, const ARowMap& arm, const BRowMap& brm, int it_begin,
                                          int it_end, char* smem) {
-  using TL = Tile<T, BM, BN, WM, WN>;
+  using TL = Tile<T, BM, BN, WM, WN, CH>;
   constexpr int TM = TL::TM, TN = TL::TN;
-  constexpr int BK = Op<T>::BK;
+  constexpr int BK = TL::BK;
   constexpr int EPC = Op<T>::EPC;
+  constexpr int KSTEP = 4 * EPC;  // contraction elements per j-block (16 for f32, 32 for bf16)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -178,7 +217,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
 
   const int nkb0 = (segs[0].K + BK - 1) / BK;
 
-  uint4 ra[BM * 8 / kThreads], rb[BN * 8 / kThreads];
+  uint4 ra[BM * CH / kThreads], rb[BN * CH / kThreads];
 
   auto seg_of = [&](int it, int& k0) -> int {
     if (it < nkb0) {
@@ -188,34 +227,34 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
     k0 = (it - nkb0) * BK;
     return 1;
   };
-  auto vec_ok = [&](const void* p, int64_t ld, int kc) -> bool {
-    return (((uintptr_t)p) & 15) == 0 && (ld % (kc ? EPC : 4)) == 0;
-  };
+  auto vec_ok = [&](const void* p, int64_t ld) -> bool { return (((uintptr_t)p) & 15) == 0 && (ld % EPC) == 0; };
   auto issue = [&](int it) {
     int k0;
     const Seg& s = segs[seg_of(it, k0)];
-    load_tile<T, BM>(ra, s.A, s.lda, s.a_kc, vec_ok(s.A, s.lda, s.a_kc), m0, M, k0, s.K, arm, s.a_rmod, tid);
-    load_tile<T, BN>(rb, s.B, s.ldb, s.b_kc, vec_ok(s.B, s.ldb, s.b_kc), n0, N, k0, s.K, brm, 0, tid);
+    load_tile<T, BM, CH>(ra, s.A, s.lda, s.a_kc, vec_ok(s.A, s.lda), m0, M, k0, s.K, arm, s.a_rmod, tid);
+    load_tile<T, BN, CH>(rb, s.B, s.ldb, s.b_kc, vec_ok(s.B, s.ldb), n0, N, k0, s.K, brm, 0, tid);
   };
 
   if (it_begin < it_end) issue(it_begin);
   for (int it = it_begin; it < it_end; ++it) {
-    int k0_unused;
-    const int si = seg_of(it, k0_unused);
+    int k0;
+    const int si = seg_of(it, k0);
     const int a_kc = segs[si].a_kc, b_kc = segs[si].b_kc;
-    store_tile<T, BM>(ra, As, a_kc, tid);
-    store_tile<T, BN>(rb, Bs, b_kc, tid);
+    const int kleft = segs[si].K - k0;
+    const int nj = kleft >= BK ? CH / 4 : (kleft + KSTEP - 1) / KSTEP;  // j-blocks that hold data
+    store_tile<T, BM, CH>(ra, As, a_kc, tid);
+    store_tile<T, BN, CH>(rb, Bs, b_kc, tid);
     __syncthreads();
-    if (it + 1 < it_end) issue(it + 1);  // next block's loads fly under this block's MFMAs
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    if (it + 1 < it_end) issue(it + 1);  // next panel's loads fly under this panel's MFMAs
+#pragma unroll 2
+    for (int j = 0; j < nj; ++j) {
       if constexpr (sizeof(T) == 4) {
         float a[TM][4], b[TN][4];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
           const int row = wm * (TM * 16) + tm * 16 + r;
           if (a_kc) {
-            uint4 u = frag_kc(As, row, j, q);
+            uint4 u = *(const uint4*)(As + kc_off<CH>(row, (j << 2) | q));
             a[tm][0] = __uint_as_float(u.x);
             a[tm][1] = __uint_as_float(u.y);
             a[tm][2] = __uint_as_float(u.z);
@@ -230,7 +269,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
         for (int tn = 0; tn < TN; ++tn) {
           const int row = wn * (TN * 16) + tn * 16 + r;
           if (b_kc) {
-            uint4 u = frag_kc(Bs, row, j, q);
+            uint4 u = *(const uint4*)(Bs + kc_off<CH>(row, (j << 2) | q));
             b[tn][0] = __uint_as_float(u.x);
             b[tn][1] = __uint_as_float(u.y);
             b[tn][2] = __uint_as_float(u.z);
@@ -249,17 +288,23 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
             for (int tn = 0; tn < TN; ++tn)
               acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
       } else {
-        // bf16: KC images only (callers guarantee); chunk (4j+q) = k 32j+8q .. +7 of this block
         bf16x8 a[TM], b[TN];
+        if (a_kc) {  // both KC (launcher guarantees a_kc == b_kc for bf16)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          uint4 u = frag_kc(As, wm * (TM * 16) + tm * 16 + r, j, q);
-          a[tm] = __builtin_bit_cast(bf16x8, u);
-        }
+          for (int tm = 0; tm < TM; ++tm) {
+            uint4 u = *(const uint4*)(As + kc_off<CH>(wm * (TM * 16) + tm * 16 + r, (j << 2) | q));
+            a[tm] = __builtin_bit_cast(bf16x8, u);
+          }
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          uint4 u = frag_kc(Bs, wn * (TN * 16) + tn * 16 + r, j, q);
-          b[tn] = __builtin_bit_cast(bf16x8, u);
+          for (int tn = 0; tn < TN; ++tn) {
+            uint4 u = *(const uint4*)(Bs + kc_off<CH>(wn * (TN * 16) + tn * 16 + r, (j << 2) | q));
+            b[tn] = __builtin_bit_cast(bf16x8, u);
+          }
+        } else {  // both KM: hardware-transposed reads
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) a[tm] = frag_km_bf16<BM + 16>(As, wm * (TM * 16) + tm * 16, j, lane);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) b[tn] = frag_km_bf16<BN + 16>(Bs, wn * (TN * 16) + tn * 16, j, lane);
         }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -280,10 +325,10 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TM][TN]) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// total number of K-blocks of a segment pair
-template <typename T>
+// total number of panels of a segment pair
+template <typename T, int CH>
 __host__ __device__ inline int num_kblocks(const Seg (&segs)[2]) {
-  constexpr int BK = Op<T>::BK;
+  constexpr int BK = CH * Op<T>::EPC;
   return (segs[0].K + BK - 1) / BK + (segs[1].K + BK - 1) / BK;
 }
 

@@ -20,6 +20,6 @@ struct GemmParams {
 
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t st);
 int pick_splitk(int64_t M, int64_t N, int64_t K);
-int launch_colsum(const float* g, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st);
+int launch_colsum(const void* g, int dtype, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st);
 
 }  // namespace fh

@@ -17,6 +17,8 @@
 
 namespace fh {
 
+constexpr int kCH = 32;  // 512-byte panels: the step GEMMs are latency-bound, pay the latency once per panel
+
 // ---------------------------------------------------------------------------------------------
 // forward cell
 // ---------------------------------------------------------------------------------------------
@@ -30,6 +32,7 @@ struct FwdJob {
   const float* c_prev;  // [B,H] or NULL (t == 0)
   float* c_out;         // [B,H]
   T* h_out;             // [B,H] operand dtype
+  float* h_out_f32;     // optional f32 copy of h (top layer in bf16 mode: feeds the f32 Gaussian head)
   float* gates_out;     // [B,4H] activated i,f,g,o
   float* hn_out;        // optional slot in the (B, L*H) final-state buffer (t == T-1)
   int64_t hn_ld;
@@ -64,7 +67,7 @@ __device__ __forceinline__ void store_h<u16>(u16* p, float v) {
 template <typename T>
 __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs) {
   constexpr int BM = 64, BN = 64, WM = 4, WN = 1;
-  using TL = Tile<T, BM, BN, WM, WN>;
+  using TL = Tile<T, BM, BN, WM, WN, kCH>;
   __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
   const FwdJob<T>& J = jobs.job[blockIdx.z];
   const int B = jobs.B, H = jobs.H;
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
   zero_acc(acc);
   RowIdent arm{B};
   GateRowMap brm{H};
-  const int nkb = num_kblocks<T>(J.seg);
-  mainloop<T, BM, BN, WM, WN>(acc, J.seg, m0, B, n0, (int)gridDim.x * 64, arm, brm, 0, nkb, smem);
+  const int nkb = num_kblocks<T, kCH>(J.seg);
+  mainloop<T, BM, BN, WM, WN, kCH>(acc, J.seg, m0, B, n0, (int)gridDim.x * 64, arm, brm, 0, nkb, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int unit = blockIdx.x * 16 + (lane & 15);
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
     const float h = og * tanhf(c);
     J.c_out[(int64_t)row * H + unit] = c;
     store_h<T>(J.h_out + (int64_t)row * H + unit, h);
+    if (J.h_out_f32) J.h_out_f32[(int64_t)row * H + unit] = h;
     float* go = J.gates_out + (int64_t)row * 4 * H + unit;
     go[0] = ig;
     go[H] = fg;
@@ -126,8 +130,7 @@ struct BwdJob {
   float* dc;            // [B,H] running dL/dc (already multiplied by f of the later step)
   int first;            // 1 at t == T-1: dc input is zero
   T* dg_out;            // [B,4H]
-  float* dg_out_f32;    // optional f32 copy (bf16 mode: operands of the f32 weight-gradient GEMMs)
-  float* dgsum;         // optional [B,4H] running sum over t (layer 0 with a time-constant input)
+  float* dgsum;         // optional [B,4H] running f32 sum over t (layer 0 with a time-constant input)
 };
 template <typename T>
 struct BwdJobs {
@@ -138,7 +141,7 @@ struct BwdJobs {
 template <typename T>
 __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs) {
   constexpr int BM = 32, BN = 32, WM = 2, WN = 2;
-  using TL = Tile<T, BM, BN, WM, WN>;
+  using TL = Tile<T, BM, BN, WM, WN, kCH>;
   __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
   const BwdJob<T>& J = jobs.job[blockIdx.z];
   const int B = jobs.B, H = jobs.H;
@@ -146,8 +149,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
   f32x4 acc[1][1];
   zero_acc(acc);
   RowIdent arm{B}, brm{H};
-  const int nkb = num_kblocks<T>(J.seg);
-  mainloop<T, BM, BN, WM, WN>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
+  const int nkb = num_kblocks<T, kCH>(J.seg);
+  mainloop<T, BM, BN, WM, WN, kCH>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -179,9 +182,31 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
     for (int g = 0; g < 4; ++g) {
       const int64_t go = (int64_t)row * 4 * H + g * H + unit;
       store_h<T>(J.dg_out + go, dp[g]);
-      if (J.dg_out_f32) J.dg_out_f32[go] = dp[g];
       if (J.dgsum) J.dgsum[go] = J.first ? dp[g] : J.dgsum[go] + dp[g];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched f32 -> bf16 cast (+ optional transposed copy): one launch for all operands of a net
+// ---------------------------------------------------------------------------------------------
+struct CastItem {
+  const float* src;
+  u16* dst;    // [R,C] or NULL
+  u16* dst_t;  // [C,R] or NULL
+  int64_t R, C;
+};
+struct CastBatch {
+  int n;
+  CastItem it[4 * FHVAE_MAX_LAYERS + 2];
+};
+__global__ void cast_batch_kernel(CastBatch cb) {
+  const CastItem& c = cb.it[blockIdx.y];
+  const int64_t n = c.R * c.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const u16 v = f2bf(c.src[i]);
+    if (c.dst) c.dst[i] = v;
+    if (c.dst_t) c.dst_t[(i % c.C) * c.R + i / c.C] = v;
   }
 }
 
@@ -212,21 +237,111 @@ static int check_desc(const fhvae_lstm_desc* d) {
   FH_CHECK_PTR(d->cs);
   FH_CHECK_PTR(d->gates);
   FH_CHECK_PTR(d->pre);
+  if (d->dtype == FHVAE_BF16) {
+    FH_CHECK_PTR(d->lp);
+    // bf16 rows are read in 16-byte chunks: every leading dimension must be a multiple of 8
+    if (d->H % 8 || (d->I + d->Ic) % 8 || d->I % 8) return FHVAE_ERR_ALIGN;
+  } else if (d->hs_top_f32) {
+    return FHVAE_ERR_SHAPE;
+  }
   return FHVAE_OK;
 }
 
+// layout of the bf16 workspace (element offsets, every block a multiple of 8 elements)
+struct LpLayout {
+  int64_t x, xc, w_ih[FHVAE_MAX_LAYERS], w_hh[FHVAE_MAX_LAYERS], w_ih_t[FHVAE_MAX_LAYERS], w_hh_t[FHVAE_MAX_LAYERS], total;
+};
+static LpLayout lp_layout(const fhvae_lstm_desc* d) {
+  LpLayout o;
+  int64_t n = 0;
+  auto take = [&](int64_t cnt) {
+    int64_t at = n;
+    n += (cnt + 7) / 8 * 8;
+    return at;
+  };
+  o.x = take(d->T * d->B * d->I);
+  o.xc = take(d->B * d->Ic);
+  for (int l = 0; l < d->L; ++l) {
+    const int64_t kin = l == 0 ? d->I + d->Ic : d->H;
+    o.w_ih[l] = take(4 * d->H * kin);
+    o.w_hh[l] = take(4 * d->H * d->H);
+    o.w_ih_t[l] = take(l == 0 ? 0 : 4 * d->H * kin);
+    o.w_hh_t[l] = take(4 * d->H * d->H);
+  }
+  o.total = n;
+  return o;
+}
+
+extern "C" int64_t fhvae_lstm_lp_bytes(const fhvae_lstm_desc* d) {
+  if (!d || d->dtype != FHVAE_BF16 || d->L < 1 || d->L > FHVAE_MAX_LAYERS) return 0;
+  return lp_layout(d).total * 2;
+}
+
+// operand views for one dtype
 template <typename T>
-static int lstm_fwd_impl(const fhvae_lstm_desc* d, hipStream_t st) {
+struct Ops {
+  const T* x;
+  const T* xc;
+  const T* w_ih[FHVAE_MAX_LAYERS];
+  const T* w_hh[FHVAE_MAX_LAYERS];
+  const T* w_ih_t[FHVAE_MAX_LAYERS];  // bf16 only
+  const T* w_hh_t[FHVAE_MAX_LAYERS];
+};
+static Ops<float> ops_f32(const fhvae_lstm_desc* d) {
+  Ops<float> o = {};
+  o.x = d->x;
+  o.xc = d->xc;
+  for (int l = 0; l < d->L; ++l) {
+    o.w_ih[l] = d->w_ih[l];
+    o.w_hh[l] = d->w_hh[l];
+  }
+  return o;
+}
+static Ops<u16> ops_bf16(const fhvae_lstm_desc* d) {
+  Ops<u16> o = {};
+  LpLayout L = lp_layout(d);
+  const u16* base = (const u16*)d->lp;
+  o.x = base + L.x;
+  o.xc = base + L.xc;
+  for (int l = 0; l < d->L; ++l) {
+    o.w_ih[l] = base + L.w_ih[l];
+    o.w_hh[l] = base + L.w_hh[l];
+    o.w_ih_t[l] = base + L.w_ih_t[l];
+    o.w_hh_t[l] = base + L.w_hh_t[l];
+  }
+  return o;
+}
+
+static int cast_operands(const fhvae_lstm_desc* d, hipStream_t st) {
+  LpLayout L = lp_layout(d);
+  u16* base = (u16*)d->lp;
+  CastBatch cb = {};
+  auto add = [&](const float* s, u16* dst, u16* dst_t, int64_t R, int64_t C) {
+    if (R * C > 0) cb.it[cb.n++] = CastItem{s, dst, dst_t, R, C};
+  };
+  add(d->x, base + L.x, nullptr, d->T * d->B, d->I);
+  add(d->xc, base + L.xc, nullptr, d->B, d->Ic);
+  for (int l = 0; l < d->L; ++l) {
+    const int64_t kin = l == 0 ? d->I + d->Ic : d->H;
+    add(d->w_ih[l], base + L.w_ih[l], l == 0 ? nullptr : base + L.w_ih_t[l], 4 * d->H, kin);
+    add(d->w_hh[l], base + L.w_hh[l], base + L.w_hh_t[l], 4 * d->H, d->H);
+  }
+  hipLaunchKernelGGL(cast_batch_kernel, dim3(64, (unsigned)cb.n), dim3(256), 0, st, cb);
+  return fh_launch_status();
+}
+
+template <typename T>
+static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t st) {
   const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
   const int L = d->L;
   const int64_t K0 = I + Ic;
-  const T* w0 = (const T*)d->w_ih[0];
+  const T* w0 = op.w_ih[0];
   // ---- layer-0 input projection (+ both biases): pre = [x_t || xc] . W_ih0^T + b_ih0 + b_hh0
   {
     GemmParams p = {};
     int s = 0;
-    if (I > 0) p.seg[s++] = Seg{d->x, I, 1, w0, K0, 1, (int)I, 0};
-    if (Ic > 0) p.seg[s++] = Seg{d->xc, Ic, 1, w0 + I, K0, 1, (int)Ic, I > 0 ? (int)B : 0};
+    if (I > 0) p.seg[s++] = Seg{op.x, I, 1, w0, K0, 1, (int)I, 0};
+    if (Ic > 0) p.seg[s++] = Seg{op.xc, Ic, 1, w0 + I, K0, 1, (int)Ic, I > 0 ? (int)B : 0};
     p.M = (int)(I > 0 ? T_ * B : B);
     p.N = (int)(4 * H);
     p.C = d->pre;
@@ -250,8 +365,8 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, hipStream_t st) {
       if (t < 0 || t >= T_) continue;
       FwdJob<T>& J = jobs.job[nj++];
       const int64_t lt = (int64_t)l * T_ + t;
-      if (l > 0) J.seg[0] = Seg{hs + ((int64_t)(l - 1) * T_ + t) * B * H, H, 1, d->w_ih[l], H, 1, (int)H, 0};
-      if (t > 0) J.seg[1] = Seg{hs + (lt - 1) * B * H, H, 1, d->w_hh[l], H, 1, (int)H, 0};
+      if (l > 0) J.seg[0] = Seg{hs + ((int64_t)(l - 1) * T_ + t) * B * H, H, 1, op.w_ih[l], H, 1, (int)H, 0};
+      if (t > 0) J.seg[1] = Seg{hs + (lt - 1) * B * H, H, 1, op.w_hh[l], H, 1, (int)H, 0};
       if (l == 0) {
         J.pre = d->pre + t * pre_tstride;
         J.pre_ld = 4 * H;
@@ -262,6 +377,7 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, hipStream_t st) {
       J.c_prev = t > 0 ? d->cs + (lt - 1) * B * H : nullptr;
       J.c_out = d->cs + lt * B * H;
       J.h_out = hs + lt * B * H;
+      if (l == L - 1 && d->hs_top_f32) J.h_out_f32 = d->hs_top_f32 + t * B * H;
       J.gates_out = d->gates + lt * B * 4 * H;
       if (d->hn && t == T_ - 1) {
         J.hn_out = d->hn + (int64_t)l * H;
@@ -279,20 +395,21 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, hipStream_t st) {
 extern "C" int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream) {
   int e = check_desc(d);
   if (e) return e;
-  if (d->dtype == FHVAE_F32) return lstm_fwd_impl<float>(d, (hipStream_t)stream);
-  return lstm_fwd_impl<u16>(d, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == FHVAE_F32) return lstm_fwd_impl<float>(d, ops_f32(d), st);
+  e = cast_operands(d, st);
+  if (e) return e;
+  return lstm_fwd_impl<u16>(d, ops_bf16(d), st);
 }
 
 template <typename T>
-static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, hipStream_t st) {
+static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;
-  const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
+  const int64_t B = d->B, T_ = d->T, Ic = d->Ic, H = d->H;
   const int L = d->L;
-  const int64_t K0 = I + Ic;
   constexpr bool kF32 = sizeof(T) == 4;
   T* dg = (T*)bd->dgates;
-  // In f32 mode the weights are read untransposed as KM operands; in bf16 mode the transposed
-  // copies [H,4H] are KC operands.
+  // f32: the weights are read untransposed as KM operands; bf16: the transposed copies [H,4H] are KC operands.
   for (int64_t w = 0; w < T_ + L - 1; ++w) {
     BwdJobs<T> jobs = {};
     jobs.B = (int)B;
@@ -306,13 +423,13 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, hipStream_t st) {
       const int64_t lt = (int64_t)l * T_ + t;
       if (t < T_ - 1) {
         const T* a = dg + (lt + 1) * B * 4 * H;
-        J.seg[0] = kF32 ? Seg{a, 4 * H, 1, d->w_hh[l], H, 0, (int)(4 * H), 0}
-                        : Seg{a, 4 * H, 1, d->w_hh_t[l], 4 * H, 1, (int)(4 * H), 0};
+        J.seg[0] = kF32 ? Seg{a, 4 * H, 1, op.w_hh[l], H, 0, (int)(4 * H), 0}
+                        : Seg{a, 4 * H, 1, op.w_hh_t[l], 4 * H, 1, (int)(4 * H), 0};
       }
       if (l < L - 1) {
         const T* a = dg + ((int64_t)(l + 1) * T_ + t) * B * 4 * H;
-        J.seg[1] = kF32 ? Seg{a, 4 * H, 1, d->w_ih[l + 1], H, 0, (int)(4 * H), 0}
-                        : Seg{a, 4 * H, 1, d->w_ih_t[l + 1], 4 * H, 1, (int)(4 * H), 0};
+        J.seg[1] = kF32 ? Seg{a, 4 * H, 1, op.w_ih[l + 1], H, 0, (int)(4 * H), 0}
+                        : Seg{a, 4 * H, 1, op.w_ih_t[l + 1], 4 * H, 1, (int)(4 * H), 0};
       }
       if (l == L - 1 && bd->d_hs_top) {
         J.ext = bd->d_hs_top + t * B * H;
@@ -338,15 +455,19 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, hipStream_t st) {
   return FHVAE_OK;
 }
 
-// weight / bias / input gradients after the recurrence (f32 operands: dgates, hs, x are f32)
-static int lstm_param_grads_f32(const fhvae_lstm_bwd_desc* bd, const float* dg, const float* hs, const float* x,
-                                const float* xc, hipStream_t st) {
+// weight / bias / input gradients after the recurrence.  The long contractions (over T*B rows) run in
+// the operand dtype (KM/KM: bf16 uses transposed LDS reads); the time-constant-input part (B rows) and
+// d_xc stay f32 (f32 dgsum).
+template <typename T>
+static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;
   const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
   const int L = d->L;
   const int64_t K0 = I + Ic, G = 4 * H;
-  auto wgrad = [&](const float* a, int64_t lda, const float* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc,
-                   int64_t Ncols) -> int {
+  const T* dg = (const T*)bd->dgates;
+  const T* hs = (const T*)d->hs;
+  auto wgrad = [&](const void* a, int64_t lda, const void* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc,
+                   int64_t Ncols, int dtype) -> int {
     // c[G, Ncols] += a[Kc, G]^T . b[Kc, Ncols]
     GemmParams p = {};
     p.seg[0] = Seg{a, lda, 0, b, ldb, 0, (int)Kc, 0};
@@ -354,34 +475,46 @@ static int lstm_param_grads_f32(const fhvae_lstm_bwd_desc* bd, const float* dg, 
     p.N = (int)Ncols;
     p.C = c;
     p.ldc = ldc;
-    p.splitk = pick_splitk(G, Ncols, Kc);
+    p.splitk = pick_splitk(G, Ncols, dtype == FHVAE_F32 ? Kc : Kc / 2);
     p.mode = p.splitk > 1 ? 2 : 1;
-    return launch_gemm(p, FHVAE_F32, st);
+    return launch_gemm(p, dtype, st);
   };
   for (int l = 0; l < L; ++l) {
-    const float* dgl = dg + (int64_t)l * T_ * B * G;
-    const float* hl = hs + (int64_t)l * T_ * B * H;
+    const T* dgl = dg + (int64_t)l * T_ * B * G;
+    const T* hl = hs + (int64_t)l * T_ * B * H;
     int e;
     if (bd->dw_hh[l] && T_ > 1) {
-      e = wgrad(dgl + B * G, G, hl, H, (T_ - 1) * B, bd->dw_hh[l], H, H);
+      e = wgrad(dgl + B * G, G, hl, H, (T_ - 1) * B, bd->dw_hh[l], H, H, d->dtype);
       if (e) return e;
     }
     if (bd->dw_ih[l]) {
       if (l > 0) {
-        e = wgrad(dgl, G, hs + (int64_t)(l - 1) * T_ * B * H, H, T_ * B, bd->dw_ih[l], H, H);
+        e = wgrad(dgl, G, hs + (int64_t)(l - 1) * T_ * B * H, H, T_ * B, bd->dw_ih[l], H, H, d->dtype);
         if (e) return e;
       } else {
         if (I > 0) {
-          e = wgrad(dgl, G, x, I, T_ * B, bd->dw_ih[0], K0, I);
+          e = wgrad(dgl, G, op.x, I, T_ * B, bd->dw_ih[0], K0, I, d->dtype);
           if (e) return e;
         }
         if (Ic > 0) {
-          e = wgrad(bd->dgsum, G, xc, Ic, B, bd->dw_ih[0] + I, K0, Ic);
+          e = wgrad(bd->dgsum, G, d->xc, Ic, B, bd->dw_ih[0] + I, K0, Ic, FHVAE_F32);
           if (e) return e;
         }
       }
     }
-    e = launch_colsum(dgl, G, bd->db_ih[l], bd->db_hh[l], T_ * B, G, st);
+    e = launch_colsum(dgl, d->dtype, G, bd->db_ih[l], bd->db_hh[l], T_ * B, G, st);
+    if (e) return e;
+  }
+  if (bd->d_xc && Ic > 0) {
+    // d_xc[B,Ic] = dgsum[B,4H] . W_ih0[:, I:]   (f32 master weight as KM operand: B(n, k) = W[k*K0 + I + n])
+    GemmParams p = {};
+    p.seg[0] = Seg{bd->dgsum, G, 1, d->w_ih[0] + I, K0, 0, (int)G, 0};
+    p.M = (int)B;
+    p.N = (int)Ic;
+    p.C = bd->d_xc;
+    p.ldc = Ic;
+    p.splitk = 1;
+    int e = launch_gemm(p, FHVAE_F32, st);
     if (e) return e;
   }
   return FHVAE_OK;
@@ -398,24 +531,13 @@ extern "C" int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* bd, void* stream) {
   if (!bd->d_hs_top && !bd->d_hn) return FHVAE_ERR_NULL;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == FHVAE_F32) {
-    e = lstm_bwd_impl<float>(bd, st);
+    Ops<float> op = ops_f32(d);
+    e = lstm_bwd_impl<float>(bd, op, st);
     if (e) return e;
-    e = lstm_param_grads_f32(bd, (const float*)bd->dgates, (const float*)d->hs, (const float*)d->x,
-                             (const float*)d->xc, st);
-    if (e) return e;
-    if (bd->d_xc && d->Ic > 0) {
-      // d_xc[B,Ic] = dgsum[B,4H] . W_ih0[:, I:]   (KM operand: B(n, k) = W[k*K0 + I + n])
-      GemmParams p = {};
-      p.seg[0] = Seg{bd->dgsum, 4 * d->H, 1, (const float*)d->w_ih[0] + d->I, d->I + d->Ic, 0, (int)(4 * d->H), 0};
-      p.M = (int)d->B;
-      p.N = (int)d->Ic;
-      p.C = bd->d_xc;
-      p.ldc = d->Ic;
-      p.splitk = 1;
-      e = launch_gemm(p, FHVAE_F32, st);
-      if (e) return e;
-    }
-    return FHVAE_OK;
+    return lstm_param_grads<float>(bd, op, st);
   }
-  return FHVAE_ERR_DTYPE;  // bf16 backward: not in this build yet
+  Ops<u16> op = ops_bf16(d);  // filled by the forward
+  e = lstm_bwd_impl<u16>(bd, op, st);
+  if (e) return e;
+  return lstm_param_grads<u16>(bd, op, st);
 }

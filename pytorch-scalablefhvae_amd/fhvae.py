@@ -52,21 +52,24 @@ class LSTMNet(nn.Module):
             raise ValueError("all layers of one LSTM net must share the hidden size (got %s)" % (hus,))
         self.lstm = LSTMParams(input_size, hus[0], len(hus))
 
-    def forward(self, x_tm, xc, T):
+    def forward(self, x_tm, xc, T, dtype=hb.F32):
         """x_tm (T,B,I) time-major or None; xc (B,Ic) constant-over-time extra input or None.
         Returns (top-layer h_t (T,B,H), concat of final h of all layers (B, L*H))."""
-        return hb.lstm_seq(x_tm, xc, T, self.lstm.flat())
+        return hb.lstm_seq(x_tm, xc, T, self.lstm.flat(), dtype)
 
 
 class FHVAE(FHVAEBase):
     def __init__(self, input_size: int, z1_hus: list, z2_hus: list, z1_dim: int, z2_dim: int, x_hus: list, *,
-                 seg_len: int = 20, num_seqs=None, reference_compat=True):
+                 seg_len: int = 20, num_seqs=None, reference_compat=True, compute_dtype: str = "f32"):
         super().__init__()
         self.model = "fhvae"
         self._init_common(z1_hus, z2_hus, z1_dim, z2_dim, x_hus, num_seqs, reference_compat)
         input_size = int(input_size)
         if input_size % seg_len:
             raise ValueError("input_size=%d is not a multiple of seg_len=%d" % (input_size, seg_len))
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError("compute_dtype must be 'f32' (exact-f32 MFMA, parity mode) or 'bf16'")
+        self.compute_dtype = compute_dtype  # MFMA operand type of the LSTM nets (master weights stay f32)
         self.seg_len = int(seg_len)         # train_model.py:120 (--seg-len, default 20)
         self.n_feat = input_size // seg_len  # input_size = T*F, train_model.py:398
         F_ = self.n_feat
@@ -91,12 +94,13 @@ class FHVAE(FHVAEBase):
         mu2_table, mu2 = self.mu2_lookup(mu_idx, self.z2_dim, num_seqs, mu2_table=mu2_table)
         e2, e1 = self._draw(eps, B, x.device)
 
+        dt = hb.BF16 if self.compute_dtype == "bf16" else hb.F32
         x_tm = hb.to_time_major(x)  # (T,B,F): contiguous per-step tiles for the step-fused cells
-        _, hn2 = self.z2_pre_encoder(x_tm, None, T)
+        _, hn2 = self.z2_pre_encoder(x_tm, None, T, dt)
         z2_mu, z2_logvar, z2_sample = self.z2_gauss_layer(hn2, e2)
-        _, hn1 = self.z1_pre_encoder(x_tm, z2_sample, T)
+        _, hn1 = self.z1_pre_encoder(x_tm, z2_sample, T, dt)
         z1_mu, z1_logvar, z1_sample = self.z1_gauss_layer(hn1, e1)
-        hs_top, _ = self.pre_decoder(None, torch.cat([z1_sample, z2_sample], dim=-1), T)
+        hs_top, _ = self.pre_decoder(None, torch.cat([z1_sample, z2_sample], dim=-1), T, dt)
         H = hs_top.shape[-1]
         x_mu, x_logvar, _ = self.dec_gauss_layer(hs_top.reshape(T * B, H), sample=False)  # (T*B, F) time-major
 

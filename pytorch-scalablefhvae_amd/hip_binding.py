@@ -33,8 +33,7 @@ class LstmDesc(C.Structure):
         ("x", _vp), ("xc", _vp),
         ("w_ih", _vp * MAX_LAYERS), ("w_hh", _vp * MAX_LAYERS),
         ("b_ih", _vp * MAX_LAYERS), ("b_hh", _vp * MAX_LAYERS),
-        ("w_ih_t", _vp * MAX_LAYERS), ("w_hh_t", _vp * MAX_LAYERS),
-        ("hs", _vp), ("cs", _vp), ("gates", _vp), ("hn", _vp), ("pre", _vp),
+        ("hs", _vp), ("cs", _vp), ("gates", _vp), ("hn", _vp), ("hs_top_f32", _vp), ("pre", _vp), ("lp", _vp),
     ]
 
 
@@ -45,7 +44,7 @@ class LstmBwdDesc(C.Structure):
         ("dgates", _vp), ("dgsum", _vp), ("dc", _vp),
         ("dw_ih", _vp * MAX_LAYERS), ("dw_hh", _vp * MAX_LAYERS),
         ("db_ih", _vp * MAX_LAYERS), ("db_hh", _vp * MAX_LAYERS),
-        ("d_xc", _vp), ("x_f32", _vp), ("xc_f32", _vp),
+        ("d_xc", _vp),
     ]
 
 
@@ -80,6 +79,7 @@ SIGNATURES = {
     "fhvae_gauss_head_reparam_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int,
                                                _vp]),
     "fhvae_gauss_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
     "fhvae_lstm_seq_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), _vp]),
     "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
@@ -322,12 +322,21 @@ def to_time_major(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _fill_lstm_desc(d, dtype, dims, x_tm, xc, params):
+    L, B, T, I, Ic, H = dims
+    d.dtype, d.L, d.B, d.T, d.I, d.Ic, d.H = dtype, L, B, T, I, Ic, H
+    d.x, d.xc = _p(x_tm), _p(xc)
+    for l in range(L):
+        d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_p(params[4 * l + k]) for k in range(4))
+
+
 class _LstmSeq(torch.autograd.Function):
     """Multi-layer LSTM over the whole segment (K1).  Inputs: x_tm (T,B,I) or None, xc (B,Ic) or None,
-    then per layer w_ih, w_hh, b_ih, b_hh.  Outputs: hs_top (T,B,H) and hn (B, L*H)."""
+    then per layer w_ih, w_hh, b_ih, b_hh (all f32).  Outputs: hs_top (T,B,H) f32 and hn (B, L*H).
+    dtype = F32 (exact-f32 MFMA) or BF16 (bf16 MFMA operands, f32 accumulate / cell state)."""
 
     @staticmethod
-    def forward(ctx, x_tm, xc, T, *params):
+    def forward(ctx, x_tm, xc, T, dtype, *params):
         lib = load_library()
         _need_gpu(x_tm, xc, *params)
         L = len(params) // 4
@@ -344,44 +353,44 @@ class _LstmSeq(torch.autograd.Function):
         assert params[0].shape == (4 * H, I + Ic), (params[0].shape, H, I, Ic)
         dev = params[0].device
         f32 = dict(device=dev, dtype=torch.float32)
-        hs = torch.empty(L, T, B, H, **f32)
+        bf = dtype == BF16
+        hs = torch.empty(L, T, B, H, device=dev, dtype=torch.bfloat16 if bf else torch.float32)
         cs = torch.empty(L, T, B, H, **f32)
         gates = torch.empty(L, T, B, 4 * H, **f32)
         hn = torch.empty(B, L * H, **f32)
         pre = torch.empty((T if I > 0 else 1), B, 4 * H, **f32)
+        hs_top = torch.empty(T, B, H, **f32) if bf else None
         d = LstmDesc()
-        d.dtype, d.L, d.B, d.T, d.I, d.Ic, d.H = F32, L, B, T, I, Ic, H
-        d.x, d.xc = _p(x_tm), _p(xc)
-        for l in range(L):
-            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_p(params[4 * l + k]) for k in range(4))
-        d.hs, d.cs, d.gates, d.hn, d.pre = _p(hs), _p(cs), _p(gates), _p(hn), _p(pre)
+        dims = (L, B, T, I, Ic, H)
+        _fill_lstm_desc(d, dtype, dims, x_tm, xc, params)
+        lp = None
+        if bf:
+            lp = torch.empty(int(lib.fhvae_lstm_lp_bytes(C.byref(d))), device=dev, dtype=torch.uint8)
+        d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.pre, d.lp = _p(hs), _p(cs), _p(gates), _p(hn), _p(hs_top), _p(pre), _p(lp)
         with _Timed("fhvae_lstm_seq_fwd"):
             _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")
-        ctx.dims = (L, B, T, I, Ic, H)
-        ctx.save_for_backward(x_tm, xc, hs, cs, gates, *params)
-        return hs[L - 1], hn
+        ctx.dims, ctx.dtype = dims, dtype
+        ctx.save_for_backward(x_tm, xc, hs, cs, gates, lp, *params)
+        return (hs_top if bf else hs[L - 1]), hn
 
     @staticmethod
     def backward(ctx, d_hs_top, d_hn):
         lib = load_library()
         L, B, T, I, Ic, H = ctx.dims
-        x_tm, xc, hs, cs, gates = ctx.saved_tensors[:5]
-        params = ctx.saved_tensors[5:]
+        x_tm, xc, hs, cs, gates, lp = ctx.saved_tensors[:6]
+        params = ctx.saved_tensors[6:]
         dev = hs.device
         f32 = dict(device=dev, dtype=torch.float32)
         if d_hs_top is None and d_hn is None:
-            return (None,) * (3 + 4 * L)
+            return (None,) * (4 + 4 * L)
         d_hs_top = _f32c(d_hs_top) if d_hs_top is not None else None
         d_hn = _f32c(d_hn) if d_hn is not None else None
         bd = LstmBwdDesc()
         d = bd.f
-        d.dtype, d.L, d.B, d.T, d.I, d.Ic, d.H = F32, L, B, T, I, Ic, H
-        d.x, d.xc = _p(x_tm), _p(xc)
-        for l in range(L):
-            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_p(params[4 * l + k]) for k in range(4))
+        _fill_lstm_desc(d, ctx.dtype, ctx.dims, x_tm, xc, params)
         pre = torch.empty(1, **f32)  # not used by the backward, must be non-NULL
-        d.hs, d.cs, d.gates, d.hn, d.pre = _p(hs), _p(cs), _p(gates), None, _p(pre)
-        dgates = torch.empty(L, T, B, 4 * H, **f32)
+        d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.pre, d.lp = _p(hs), _p(cs), _p(gates), None, None, _p(pre), _p(lp)
+        dgates = torch.empty(L, T, B, 4 * H, device=dev, dtype=hs.dtype)
         dgsum = torch.empty(B, 4 * H, **f32) if Ic > 0 else None
         dc = torch.empty(L, B, H, **f32)
         grads = [torch.zeros_like(p) for p in params]
@@ -393,11 +402,11 @@ class _LstmSeq(torch.autograd.Function):
         bd.d_xc = _p(d_xc)
         with _Timed("fhvae_lstm_seq_bwd"):
             _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
-        return (None, d_xc, None, *grads)
+        return (None, d_xc, None, None, *grads)
 
 
-def lstm_seq(x_tm, xc, T, params: Sequence[torch.Tensor]):
-    return _LstmSeq.apply(x_tm, xc, int(T), *params)
+def lstm_seq(x_tm, xc, T, params: Sequence[torch.Tensor], dtype: int = F32):
+    return _LstmSeq.apply(x_tm, xc, int(T), int(dtype), *params)
 
 
 class _Mu2Gather(torch.autograd.Function):

@@ -121,3 +121,29 @@ def test_persistent_table_trains(hb):
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert m.mu2_table.grad is not None and m.pre_decoder.lstm.weight_hh_l1.grad.abs().sum() > 0
+
+
+def test_fhvae_bf16_tracks_f32(hb):
+    """bf16 MFMA operands (compute_dtype='bf16') against the f32 oracle: the bound and the loss agree to 1e-2
+    relative ("matched ELBO" tolerance for the bf16 configs)."""
+    from fhvae import FHVAE
+    from train_model import loss_function
+
+    T, F, H, D, B, S = 20, 80, 256, 32, 64, 500
+    torch.manual_seed(5)
+    ref = R.FHVAERef(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T)
+    m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T, reference_compat=False, compute_dtype="bf16")
+    m.load_state_dict(ref.state_dict(), strict=False)
+    m.cuda()
+    x, idx, ns = torch.randn(B, T, F), torch.randint(0, S, (B,)), torch.randint(3, 100, (B,))
+    table, e2, e1 = torch.randn(S, D), torch.randn(B, D), torch.randn(B, D)
+    with torch.no_grad():
+        want = ref(x, idx, S, ns, mu2_table=table, eps_z2=e2, eps_z1=e1, reference_compat=False)
+    td = dev(table).requires_grad_(True)
+    got = m(dev(x), idx, S, ns, mu2_table=td, eps=(e2, e1))
+    for k, n in enumerate(OUT):
+        close(got[k], want[k], rtol=1e-2, what=n)
+    loss = loss_function(got[0], got[1], 10.0)
+    close(loss, R.loss_function(want[0], want[1], 10.0), rtol=1e-2, what="loss")
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for n, p in m.named_parameters() if n != "mu2_table")
