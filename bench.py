@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="MFMA operand type of the LSTM nets (configs[1] is quoted in bf16; f32 = exact-f32 parity mode)")
+    ap.add_argument("--force-dist", action="store_true", help="use the distributed runner even with one rank (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -99,9 +100,12 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
 
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     import hip_binding as hb
@@ -118,7 +122,7 @@ def main():
                   compute_dtype=args.dtype).to(device)
     with torch.no_grad():
         model.mu2_table.copy_(torch.randn(S, D, generator=torch.Generator().manual_seed(1)))
-    if world > 1:
+    if use_dist:
         from dist_shard import DistributedFHVAE
 
         runner = DistributedFHVAE(model, lr=1e-3, betas=(0.95, 0.999))
@@ -138,7 +142,7 @@ def main():
         return loss.detach(), out[0].detach()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
 
             dist.barrier()
@@ -152,7 +156,7 @@ def main():
         loss, lb = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -190,14 +194,14 @@ def main():
             "dtype": args.dtype, "data": "synthetic", "elbo_nats_per_frame": elbo, "loss_finite": ok,
             "config": {"workload": "%s: %s; per-GPU batch %d, T=%d, F=%d, full train step (fwd+loss+bwd+Adam), "
                                    "intended objective" % (args.config, cfg["desc"], B, T, F),
-                       "global_batch": world * B, "parallelism": "dp%d+mu2-row-shard" % world if world > 1 else "single"},
+                       "global_batch": world * B, "parallelism": "dp%d+mu2-row-shard" % world if use_dist else "single"},
         }
         if roof:
             rec["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(cfg, B)
         print(json.dumps(rec))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         dist.destroy_process_group()

@@ -138,14 +138,16 @@ int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * mu2 gather (K4): mu2[b,:] = table[idx[b],:]  -- torch.gather, simple_fhvae.py:53.
- * bwd: dtable[idx[b],:] += dmu2[b,:] (float atomics; duplicate indices accumulate).
+ * bwd: dtable[idx[b],:] += scale * dmu2[b,:] (float atomics; duplicate indices accumulate; rows
+ * outside [0,S) are skipped, which is how a row shard ignores other shards' rows).
+ * fwd/bwd take idx RELATIVE to the table passed (a shard passes idx - row0 via `idx_offset`).
  * idx is int64 (DataLoader collate, train_model.py:445); rows outside [0,S) -> error flag:
  * the kernel writes zeros for them and sets *oob_flag (int32 device word, may be NULL).
  * ------------------------------------------------------------------------------------------ */
-int fhvae_mu2_gather_fwd(const float* table, const int64_t* idx, float* mu2, int64_t B, int64_t S,
-                         int64_t D, int32_t* oob_flag, void* stream);
-int fhvae_mu2_gather_bwd(const float* dmu2, const int64_t* idx, float* dtable, int64_t B, int64_t S,
-                         int64_t D, void* stream);
+int fhvae_mu2_gather_fwd(const float* table, const int64_t* idx, int64_t idx_offset, float* mu2,
+                         int64_t B, int64_t S, int64_t D, int32_t* oob_flag, void* stream);
+int fhvae_mu2_gather_bwd(const float* dmu2, const int64_t* idx, int64_t idx_offset, float* dtable,
+                         int64_t B, int64_t S, int64_t D, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused variational lower bound (K3) -- simple_fhvae.py:105-116 with log_gauss :56-60, kld :62-69.
@@ -202,6 +204,14 @@ int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S);
 int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
                        float inv_two_var, float* row_max, float* row_sumexp, float* tgt_logit,
                        float* ce_mean, void* ws, int64_t B, int64_t S, int64_t D, void* stream);
+/* Cross-shard combine helpers (multi-GPU): after an all-reduce(MAX) of row_max over the
+ * shards, rescale a shard's sum to the global max:  out[b] = rsum_local[b] * exp(rmax_local[b] - m_global[b]);
+ * after the all-reduce(SUM) of (out, tgt): ce = mean_b((m - tgt) + log s), single workgroup, deterministic. */
+int fhvae_disc_lse_rescale(const float* rmax_local, const float* rsum_local, const float* m_global,
+                           float* out, int64_t B, void* stream);
+int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp, const float* tgt_logit,
+                       float* ce_mean, int64_t B, void* stream);
+
 /* bwd: given the GLOBAL (all shards combined) row_max[b] and row_sumexp[b] and the scalar scale
  * g = (*g_scale) * g_mul  (= dL/d(ce_mean) / B_total), computes  p[b,s] = exp(logit - row_max[b]) / row_sumexp[b]
  * (kept as max and sum, not as one log-sum-exp: |max| ~ 1e3 would put its ulp into every p),

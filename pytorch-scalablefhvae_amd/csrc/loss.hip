@@ -39,12 +39,12 @@ __global__ void cast_bf16_kernel(const float* __restrict__ s, u16* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // K4 gather / scatter-add
 // ---------------------------------------------------------------------------------------------
-__global__ void gather_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
+__global__ void gather_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, int64_t off,
                                   float* __restrict__ out, int64_t B, int64_t S, int64_t D, int32_t* oob) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * D) return;
   int64_t b = i / D, d = i % D;
-  int64_t s = idx[b];
+  int64_t s = idx[b] - off;
   if (s < 0 || s >= S) {
     out[i] = 0.f;
     if (oob && d == 0) atomicOr(oob, 1);
@@ -53,14 +53,14 @@ __global__ void gather_fwd_kernel(const float* __restrict__ table, const int64_t
   out[i] = table[s * D + d];
 }
 
-__global__ void gather_bwd_kernel(const float* __restrict__ dmu2, const int64_t* __restrict__ idx,
-                                  float* __restrict__ dtable, int64_t B, int64_t S, int64_t D) {
+__global__ void gather_bwd_kernel(const float* __restrict__ dmu2, const int64_t* __restrict__ idx, int64_t off,
+                                  float* __restrict__ dtable, int64_t B, int64_t S, int64_t D, float scale) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * D) return;
   int64_t b = i / D, d = i % D;
-  int64_t s = idx[b];
+  int64_t s = idx[b] - off;
   if (s < 0 || s >= S) return;
-  atomicAdd(dtable + s * D + d, dmu2[i]);
+  atomicAdd(dtable + s * D + d, scale * dmu2[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -285,6 +285,12 @@ __global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) / (float)B;
 }
 
+__global__ void disc_rescale_kernel(const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                    const float* __restrict__ m, float* __restrict__ out, int64_t B) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = rsum[i] * __expf(rmax[i] - m[i]);
+}
+
 // Backward, query side: dq[b,:] = -2c * sum_s w_bs (q_b - t_s), w = g (p - onehot)
 template <int D>
 __global__ __launch_bounds__(256) void disc_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ table,
@@ -448,8 +454,8 @@ extern "C" int fhvae_cast_bf16(const float* src, void* dst, void* dst_t, int64_t
   return fh_launch_status();
 }
 
-extern "C" int fhvae_mu2_gather_fwd(const float* table, const int64_t* idx, float* mu2, int64_t B, int64_t S, int64_t D,
-                                    int32_t* oob_flag, void* stream) {
+extern "C" int fhvae_mu2_gather_fwd(const float* table, const int64_t* idx, int64_t idx_offset, float* mu2, int64_t B,
+                                    int64_t S, int64_t D, int32_t* oob_flag, void* stream) {
   FH_CHECK_PTR(table);
   FH_CHECK_PTR(idx);
   FH_CHECK_PTR(mu2);
@@ -457,12 +463,12 @@ extern "C" int fhvae_mu2_gather_fwd(const float* table, const int64_t* idx, floa
   FH_CHECK_POS(S);
   FH_CHECK_POS(D);
   hipLaunchKernelGGL(gather_fwd_kernel, dim3((unsigned)fh_cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, table, idx,
-                     mu2, B, S, D, oob_flag);
+                     idx_offset, mu2, B, S, D, oob_flag);
   return fh_launch_status();
 }
 
-extern "C" int fhvae_mu2_gather_bwd(const float* dmu2, const int64_t* idx, float* dtable, int64_t B, int64_t S, int64_t D,
-                                    void* stream) {
+extern "C" int fhvae_mu2_gather_bwd(const float* dmu2, const int64_t* idx, int64_t idx_offset, float* dtable, int64_t B,
+                                    int64_t S, int64_t D, float scale, void* stream) {
   FH_CHECK_PTR(dmu2);
   FH_CHECK_PTR(idx);
   FH_CHECK_PTR(dtable);
@@ -470,7 +476,7 @@ extern "C" int fhvae_mu2_gather_bwd(const float* dmu2, const int64_t* idx, float
   FH_CHECK_POS(S);
   FH_CHECK_POS(D);
   hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)fh_cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, dmu2, idx,
-                     dtable, B, S, D);
+                     idx_offset, dtable, B, S, D, scale);
   return fh_launch_status();
 }
 
@@ -567,6 +573,31 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
     e = fh_launch_status();
   }
   return e;
+}
+
+extern "C" int fhvae_disc_lse_rescale(const float* rmax_local, const float* rsum_local, const float* m_global, float* out,
+                                      int64_t B, void* stream) {
+  FH_CHECK_PTR(rmax_local);
+  FH_CHECK_PTR(rsum_local);
+  FH_CHECK_PTR(m_global);
+  FH_CHECK_PTR(out);
+  FH_CHECK_POS(B);
+  hipLaunchKernelGGL(disc_rescale_kernel, dim3((unsigned)fh_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, rmax_local,
+                     rsum_local, m_global, out, B);
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp, const float* tgt_logit, float* ce_mean,
+                                  int64_t B, void* stream) {
+  FH_CHECK_PTR(row_max);
+  FH_CHECK_PTR(row_sumexp);
+  FH_CHECK_PTR(tgt_logit);
+  FH_CHECK_PTR(ce_mean);
+  FH_CHECK_POS(B);
+  FH_CHECK_I32(B);
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_max, row_sumexp, tgt_logit, ce_mean,
+                     (int)B);
+  return fh_launch_status();
 }
 
 extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float inv_two_var,

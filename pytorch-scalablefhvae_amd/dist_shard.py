@@ -1,0 +1,193 @@
+"""Multi-GPU: data parallel over the minibatch + row-sharded mu2 table.
+
+One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm).  Net weights are
+replicated; rank r owns table rows [row0, row1) and their Adam moments.  Per training step:
+
+  forward   all-gather idx, z2_mu (B_local*D*4 bytes per rank)            -- C2 of SURVEY 8e
+            rows   : owners gather their rows for ALL global queries, reduce-scatter -> mu2 of the local batch
+            K5     : each rank scans ITS rows for all global queries -> (max, sumexp, target) partials,
+                     all-reduce(MAX) max, rescale, all-reduce(SUM) (sumexp, target) -> CE (same on all ranks)
+  backward  dtable : local rows, complete, no exchange;   dq : reduce-scatter to the query's owner
+            dmu2   : all-gather, owners scatter-add
+            nets   : ONE all-reduce over the flat gradient arena; 1/W is folded into Adam's grad_scale
+All exchanged messages are O(B*D): latency-bound on xGMI, no table rows ever move.
+
+The local arithmetic goes through a `backend` object.  The product backend is `HipBackend` (the HIP kernels);
+tests pass an oracle backend to exercise the collective logic on CPU with gloo.  There is no automatic
+fallback: `DistributedFHVAE` always uses `HipBackend`.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class HipBackend:
+    """Local compute on the HIP kernels (include/fhvae_hip.h)."""
+
+    def __init__(self):
+        import hip_binding as hb
+
+        hb.load_library()
+        self.hb = hb
+
+    def gather_rows(self, shard, idx_all, row0):
+        return self.hb.raw_gather_rows(shard, idx_all, row0)
+
+    def scatter_rows_(self, dshard, drows, idx_all, row0, scale):
+        self.hb.raw_scatter_rows_(dshard, drows, idx_all, row0, scale)
+
+    def disc_partials(self, q_all, shard, idx_all, row0):
+        rmax, rsum, tgt, _ = self.hb.raw_disc_fwd(q_all, shard, idx_all, row0=row0, want_ce=False)
+        return rmax, rsum, tgt
+
+    def disc_rescale(self, rmax, rsum, m):
+        return self.hb.raw_disc_rescale(rmax, rsum, m)
+
+    def ce_mean(self, m, s, tgt):
+        return self.hb.raw_disc_ce_mean(m, s, tgt)
+
+    def disc_bwd(self, q_all, shard, idx_all, row0, m, s, g, g_mul, need_dq, need_dt):
+        return self.hb.raw_disc_bwd(q_all, shard, idx_all, m, s, g, g_mul, row0=row0, need_dq=need_dq, need_dt=need_dt)
+
+
+class ShardCtx:
+    def __init__(self, num_seqs: int, group=None, backend=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.S = int(num_seqs)
+        self.per = (self.S + self.world - 1) // self.world
+        self.row0 = min(self.S, self.rank * self.per)
+        self.row1 = min(self.S, self.row0 + self.per)
+        self.backend = backend
+        self.is_gloo = dist.get_backend(group) == "gloo"
+
+    # -- collectives over dim 0, equal sizes on every rank --------------------------------------
+    def all_gather(self, x: torch.Tensor) -> torch.Tensor:
+        out = x.new_empty((self.world * x.shape[0],) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
+        return out
+
+    def reduce_scatter(self, x_all: torch.Tensor) -> torch.Tensor:
+        n = x_all.shape[0] // self.world
+        if self.is_gloo:  # gloo has no reduce_scatter: all-reduce and keep the own slice
+            dist.all_reduce(x_all, group=self.group)
+            return x_all[self.rank * n:(self.rank + 1) * n].clone()
+        out = x_all.new_empty((n,) + tuple(x_all.shape[1:]))
+        dist.reduce_scatter_tensor(out, x_all.contiguous(), group=self.group)
+        return out
+
+
+class _ShardGather(torch.autograd.Function):
+    """mu2 rows of the local batch out of the row-sharded table (replaces torch.gather, simple_fhvae.py:53)."""
+
+    @staticmethod
+    def forward(ctx, shard, idx_all, sh: ShardCtx):
+        rows_all = sh.backend.gather_rows(shard, idx_all, sh.row0)  # zeros for rows owned elsewhere
+        ctx.sh, ctx.shape = sh, tuple(shard.shape)
+        ctx.save_for_backward(idx_all)
+        return sh.reduce_scatter(rows_all)
+
+    @staticmethod
+    def backward(ctx, dmu2):
+        sh = ctx.sh
+        (idx_all,) = ctx.saved_tensors
+        d_all = sh.all_gather(dmu2.contiguous())
+        dshard = torch.zeros(ctx.shape, device=dmu2.device, dtype=dmu2.dtype)
+        # the objective is the mean over ranks of the local losses: 1/W on every rank's contribution
+        sh.backend.scatter_rows_(dshard, d_all, idx_all, sh.row0, 1.0 / sh.world)
+        return dshard, None, None
+
+
+class _ShardDisc(torch.autograd.Function):
+    """log-sum-exp cross-entropy of the local queries against the WHOLE (sharded) table; returns the mean
+    over the GLOBAL batch (identical on every rank) -- simple_fhvae.py:119-122."""
+
+    @staticmethod
+    def forward(ctx, q_local, shard, idx_all, sh: ShardCtx):
+        be = sh.backend
+        q_all = sh.all_gather(q_local.detach())
+        rmax, rsum, tgt = be.disc_partials(q_all, shard, idx_all, sh.row0)
+        m = rmax.clone()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=sh.group)
+        st = torch.stack([be.disc_rescale(rmax, rsum, m), tgt])
+        dist.all_reduce(st, group=sh.group)
+        ce = be.ce_mean(m, st[0].contiguous(), st[1].contiguous())
+        ctx.sh = sh
+        ctx.save_for_backward(q_all, shard, idx_all, m, st[0].contiguous())
+        return ce
+
+    @staticmethod
+    def backward(ctx, g):
+        sh, be = ctx.sh, ctx.sh.backend
+        q_all, shard, idx_all, m, s = ctx.saved_tensors
+        g = g.reshape(1).contiguous()
+        n_all = q_all.shape[0]
+        n_loc = n_all // sh.world
+        dq_local = dshard = None
+        if ctx.needs_input_grad[0]:
+            # net gradients are averaged over ranks afterwards, so the query side carries W/B_global = 1/B_local
+            dq_all, _ = be.disc_bwd(q_all, shard, idx_all, sh.row0, m, s, g, 1.0 / n_loc, True, False)
+            dq_local = sh.reduce_scatter(dq_all)
+        if ctx.needs_input_grad[1]:
+            # the shard's gradient is complete locally (all global queries were scanned): true scale 1/B_global
+            _, dshard = be.disc_bwd(q_all, shard, idx_all, sh.row0, m, s, g, 1.0 / n_all, False, True)
+        return dq_local, dshard, None, None
+
+
+class ShardedTableOps:
+    """Plugs into FHVAEBase (`model.table_ops`): same two calls as the single-GPU ops."""
+
+    def __init__(self, shard: nn.Parameter, sh: ShardCtx):
+        self.shard, self.sh = shard, sh
+        self._idx_all = None
+
+    def lookup(self, mu_idx, num_seqs, mu2_table=None):
+        if mu2_table is not None:
+            raise ValueError("mu2_table injection is a single-GPU parity feature")
+        if int(num_seqs) != self.sh.S:
+            raise ValueError("num_seqs=%d does not match the sharded table (%d rows)" % (num_seqs, self.sh.S))
+        self._idx_all = self.sh.all_gather(mu_idx)
+        return self.shard, _ShardGather.apply(self.shard, self._idx_all, self.sh)
+
+    def disc(self, z2_mu, table, mu_idx):
+        return _ShardDisc.apply(z2_mu, self.shard, self._idx_all, self.sh)
+
+
+class DistributedFHVAE:
+    """Wraps a drop-in model (fhvae.FHVAE / simple_fhvae.SimpleFHVAE built with num_seqs=S on this rank's GPU)
+    for one-process-per-GPU training.  Every rank must construct the model with the same seed."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.95, 0.999), eps=1e-8, group=None):
+        from hip_optim import FusedAdam
+
+        if model.mu2_table is None:
+            raise ValueError("build the model with num_seqs= so the table exists")
+        self.model = model
+        self.sh = ShardCtx(model.mu2_table.shape[0], group, HipBackend())
+        full = model.mu2_table.data
+        self.shard = nn.Parameter(full[self.sh.row0:self.sh.row1].clone())
+        model.mu2_table = None  # the full table is dropped: only the shard stays resident
+        model.table_ops = ShardedTableOps(self.shard, self.sh)
+        nets = [p for p in model.parameters() if p.requires_grad]
+        for p in nets:  # replicas start identical
+            dist.broadcast(p.data, 0, group=group)
+        self.opt_nets = FusedAdam(nets, lr=lr, betas=betas, eps=eps, grad_scale=1.0 / self.sh.world)
+        self.opt_table = FusedAdam([self.shard], lr=lr, betas=betas, eps=eps, grad_scale=1.0)
+
+    def train_step(self, x, idx, nsegs, alpha=10.0):
+        from train_model import loss_function
+
+        self.opt_nets.zero_grad()
+        self.opt_table.zero_grad()
+        out = self.model(x, idx, self.sh.S, nsegs)
+        loss = loss_function(out[0], out[1], alpha)
+        loss.backward()
+        dist.all_reduce(self.opt_nets.flat_grad(), group=self.sh.group)  # C1: one collective over the arena
+        self.opt_nets.step()
+        self.opt_table.step()
+        return loss.detach(), out[0].detach()

@@ -82,9 +82,9 @@ class FHVAE(FHVAEBase):
         self.dec_gauss_layer = GaussianLayer(self.x_hus[-1], F_)
         self._maybe_create_table()
 
-    def mu2_lookup(self, mu_idx, z2_dim, num_seqs, init_std: float = 1.0, mu2_table=None):
-        table = mu2_table if mu2_table is not None else self._table(num_seqs, mu_idx.device)
-        return table, hb.mu2_gather(table, mu_idx)
+    def mu2_lookup(self, mu_idx: torch.Tensor, z2_dim: int, num_seqs: int, init_std: float = 1.0, mu2_table=None):
+        """Table + gathered rows (simple_fhvae.py:39-54); the table persists instead of being redrawn."""
+        return self.table_ops.lookup(mu_idx, num_seqs, mu2_table)
 
     def forward(self, x: torch.Tensor, mu_idx: torch.Tensor, num_seqs: int, num_segs, *, mu2_table=None, eps=None):
         x, mu_idx, num_segs = self._prep_inputs(x, mu_idx, num_segs)

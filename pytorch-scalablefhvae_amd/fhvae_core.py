@@ -17,6 +17,20 @@ PMU2_LOGVAR = np.log(1.0 ** 2).astype(np.float32)  # simple_fhvae.py:23
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)   # simple_fhvae.py:88
 
 
+class LocalTableOps:
+    """Single-GPU mu2-table ops: gather (K4) and discriminative CE (K5) against the whole table."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def lookup(self, mu_idx, num_seqs, mu2_table=None):
+        table = mu2_table if mu2_table is not None else self.model._table(num_seqs, mu_idx.device)
+        return table, hb.mu2_gather(table, mu_idx)
+
+    def disc(self, z2_mu, table, mu_idx):
+        return hb.disc_lse(z2_mu, table, mu_idx)
+
+
 class FHVAEBase(nn.Module):
     """Common constructor surface and loss tail.
 
@@ -44,6 +58,7 @@ class FHVAEBase(nn.Module):
         self.pmu2 = [0.0, PMU2_LOGVAR]
         self.reference_compat = bool(reference_compat)
         self._init_num_seqs = num_seqs
+        self.table_ops = LocalTableOps(self)  # dist_shard.DistributedFHVAE swaps in the row-sharded ops
 
     def _maybe_create_table(self):
         # called at the END of __init__ so that the nets' default init consumes the RNG first
@@ -88,7 +103,7 @@ class FHVAEBase(nn.Module):
         """simple_fhvae.py:105-124 on the HIP kernels."""
         rc = self.reference_compat
         lb, lpx, nk1, nk2, lpm = hb.elbo(x_like, x_mu, x_lv, z1[0], z1[1], z2[0], z2[1], mu2, num_segs, layout, rc)
-        ce = hb.disc_lse(z2[0], table, mu_idx)
+        ce = self.table_ops.disc(z2[0], table, mu_idx)
         log_qy = ce if rc else -ce
         self.qz2_x = [z2[0], z2[1]]      # read by estimate_mu2_dict, utils.py:52
         self.pz2 = [mu2, PZ2_LOGVAR]     # utils.py:58

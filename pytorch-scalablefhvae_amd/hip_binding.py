@@ -82,8 +82,10 @@ SIGNATURES = {
     "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
     "fhvae_lstm_seq_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), _vp]),
-    "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
-    "fhvae_mu2_gather_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "fhvae_mu2_gather_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp]),
+    "fhvae_disc_lse_rescale": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "fhvae_disc_ce_mean": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "fhvae_elbo_fwd": (C.c_int, [C.POINTER(ElboDesc), _vp]),
     "fhvae_elbo_bwd": (C.c_int, [C.POINTER(ElboBwdDesc), _vp]),
     "fhvae_disc_lse_ws_bytes": (_i64, [_i64, _i64]),
@@ -409,32 +411,45 @@ def lstm_seq(x_tm, xc, T, params: Sequence[torch.Tensor], dtype: int = F32):
     return _LstmSeq.apply(x_tm, xc, int(T), int(dtype), *params)
 
 
+def raw_gather_rows(table, idx, idx_offset=0):
+    """rows = table[idx - idx_offset], zeros where the row is outside the table (a shard's view)."""
+    lib = load_library()
+    S, D = table.shape
+    B = idx.shape[0]
+    out = torch.empty(B, D, device=table.device, dtype=torch.float32)
+    with _Timed("fhvae_mu2_gather_fwd"):
+        _check(lib.fhvae_mu2_gather_fwd(_p(table), _p(idx), idx_offset, _p(out), B, S, D, None, _stream()),
+               "fhvae_mu2_gather_fwd")
+    return out
+
+
+def raw_scatter_rows_(dtable, drows, idx, idx_offset=0, scale=1.0):
+    """dtable[idx - idx_offset] += scale * drows (rows outside the table skipped)."""
+    lib = load_library()
+    S, D = dtable.shape
+    with _Timed("fhvae_mu2_gather_bwd"):
+        _check(lib.fhvae_mu2_gather_bwd(_p(drows), _p(idx), idx_offset, _p(dtable), idx.shape[0], S, D, float(scale),
+                                        _stream()), "fhvae_mu2_gather_bwd")
+
+
 class _Mu2Gather(torch.autograd.Function):
     """mu2 = table[idx] -- simple_fhvae.py:53."""
 
     @staticmethod
     def forward(ctx, table, idx):
         _need_gpu(table, idx)
-        lib = load_library()
         table = _f32c(table)
-        S, D = table.shape
-        B = idx.shape[0]
-        out = torch.empty(B, D, device=table.device, dtype=torch.float32)
-        with _Timed("fhvae_mu2_gather_fwd"):
-            _check(lib.fhvae_mu2_gather_fwd(_p(table), _p(idx), _p(out), B, S, D, None, _stream()), "fhvae_mu2_gather_fwd")
+        out = raw_gather_rows(table, idx)
         ctx.save_for_backward(idx)
-        ctx.shape = (S, D)
+        ctx.shape = tuple(table.shape)
         return out
 
     @staticmethod
     def backward(ctx, dmu2):
-        lib = load_library()
         (idx,) = ctx.saved_tensors
-        S, D = ctx.shape
         dmu2 = _f32c(dmu2)
-        dt = torch.zeros(S, D, device=dmu2.device, dtype=torch.float32)
-        with _Timed("fhvae_mu2_gather_bwd"):
-            _check(lib.fhvae_mu2_gather_bwd(_p(dmu2), _p(idx), _p(dt), idx.shape[0], S, D, _stream()), "fhvae_mu2_gather_bwd")
+        dt = torch.zeros(ctx.shape, device=dmu2.device, dtype=torch.float32)
+        raw_scatter_rows_(dt, dmu2, idx)
         return dt, None
 
 
@@ -530,6 +545,23 @@ def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True
         _check(lib.fhvae_disc_lse_bwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(g_scale), float(g_mul),
                                       _p(dq), _p(dt), None, B, S, D, _stream()), "fhvae_disc_lse_bwd")
     return dq, dt
+
+
+def raw_disc_rescale(rmax_local, rsum_local, m_global):
+    lib = load_library()
+    out = torch.empty_like(rsum_local)
+    with _Timed("fhvae_disc_lse_rescale"):
+        _check(lib.fhvae_disc_lse_rescale(_p(rmax_local), _p(rsum_local), _p(m_global), _p(out), out.numel(), _stream()),
+               "fhvae_disc_lse_rescale")
+    return out
+
+
+def raw_disc_ce_mean(m, s, tgt):
+    lib = load_library()
+    ce = torch.empty((), device=m.device, dtype=torch.float32)
+    with _Timed("fhvae_disc_ce_mean"):
+        _check(lib.fhvae_disc_ce_mean(_p(m), _p(s), _p(tgt), _p(ce), m.numel(), _stream()), "fhvae_disc_ce_mean")
+    return ce
 
 
 class _DiscLse(torch.autograd.Function):

@@ -100,8 +100,7 @@ class SimpleFHVAE(FHVAEBase):
 
     def mu2_lookup(self, mu_idx: torch.Tensor, z2_dim: int, num_seqs: int, init_std: float = 1.0, mu2_table=None):
         """Table + gathered rows (simple_fhvae.py:39-54); the table persists instead of being redrawn."""
-        table = mu2_table if mu2_table is not None else self._table(num_seqs, mu_idx.device)
-        return table, hb.mu2_gather(table, mu_idx)
+        return self.table_ops.lookup(mu_idx, num_seqs, mu2_table)
 
     def forward(self, x: torch.Tensor, mu_idx: torch.Tensor, num_seqs: int, num_segs, *, mu2_table=None, eps=None):
         x, mu_idx, num_segs = self._prep_inputs(x, mu_idx, num_segs)

@@ -53,7 +53,7 @@ def test_struct_layouts_match_header(lib):
 def test_argument_errors_are_reported_before_any_launch(lib):
     # NULL pointers / bad shapes return negative codes on the host: nothing touches a GPU
     assert lib.fhvae_linear_fwd(None, 1, None, 1, None, None, 1, None, 1, 1, 1, 0, 0, None) == -1
-    assert lib.fhvae_mu2_gather_fwd(None, None, None, 1, 1, 1, None, None) == -1
+    assert lib.fhvae_mu2_gather_fwd(None, None, 0, None, 1, 1, 1, None, None) == -1
     assert lib.fhvae_disc_lse_ws_bytes(256, 4600) > 0
     assert lib.fhvae_lstm_seq_fwd(None, None) == -1
     import hip_binding as hb

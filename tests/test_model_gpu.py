@@ -147,3 +147,49 @@ def test_fhvae_bf16_tracks_f32(hb):
     close(loss, R.loss_function(want[0], want[1], 10.0), rtol=1e-2, what="loss")
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for n, p in m.named_parameters() if n != "mu2_table")
+
+
+def test_distributed_wrapper_world1_matches_single_gpu(hb):
+    """dist_shard.DistributedFHVAE on a 1-rank RCCL group (the HipBackend code path of the sharded ops):
+    same losses as the plain single-GPU loop over several Adam steps."""
+    import torch.distributed as dist
+    from dist_shard import DistributedFHVAE
+    from fhvae import FHVAE
+    from hip_optim import FusedAdam
+    from train_model import loss_function
+
+    T, F, H, D, B, S = 20, 80, 32, 16, 48, 37
+    x = torch.randn(B, T, F, generator=torch.Generator().manual_seed(1)).cuda()
+    idx = torch.randint(0, S, (B,), generator=torch.Generator().manual_seed(2)).cuda()
+    ns = torch.randint(20, 200, (B,), generator=torch.Generator().manual_seed(3)).cuda()
+    eps = (torch.randn(B, D, generator=torch.Generator().manual_seed(4)).cuda(),
+           torch.randn(B, D, generator=torch.Generator().manual_seed(5)).cuda())
+
+    def build():
+        torch.manual_seed(11)
+        return FHVAE(T * F, [H, H], [H, H], D, D, [H, H], num_seqs=S, reference_compat=False).cuda()
+
+    m1 = build()
+    opt = FusedAdam(m1.parameters(), lr=1e-3, betas=(0.95, 0.999))
+    ref_losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = m1(x, idx, S, ns, eps=eps)
+        loss = loss_function(out[0], out[1], 10.0)
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        m2 = build()
+        runner = DistributedFHVAE(m2, lr=1e-3, betas=(0.95, 0.999))
+        fwd = m2.forward
+        m2.forward = lambda *a, **k: fwd(*a, eps=eps, **k)  # same draws as the reference loop
+        got = [runner.train_step(x, idx, ns, alpha=10.0)[0].item() for _ in range(3)]
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(got, ref_losses):
+        assert abs(a - b) <= 1e-4 * abs(b), (got, ref_losses)
+    close(runner.shard, m1.mu2_table, rtol=1e-4, what="table after 3 steps")
