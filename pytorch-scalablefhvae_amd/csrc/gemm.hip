@@ -9,14 +9,28 @@ namespace fh {
 // ---------------------------------------------------------------------------------------------
 // generic GEMM kernel: C = epi(sum_seg A.B^T)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int CH>
+__device__ __forceinline__ void gemm_store(const GemmParams& p, int row, int col, float v) {
+  if (p.relu) v = fmaxf(v, 0.f);
+  if (p.C) {
+    float* c = p.C + (int64_t)row * p.ldc + col;
+    if (p.mode == 0)
+      *c = v;
+    else if (p.mode == 1)
+      *c += v;
+    else
+      atomicAdd(c, v);
+  }
+  if (p.Clp) p.Clp[(int64_t)row * p.ldclp + col] = f2bf(v);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC>
 __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   using TL = Tile<T, BM, BN, WM, WN, CH>;
   constexpr int TM = TL::TM, TN = TL::TN;
   __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int nkb = num_kblocks<T, CH>(p.seg);
-  // split-K: contiguous ranges of K-blocks per z-slice
+  // split-K: contiguous ranges of panels per z-slice
   const int per = (nkb + p.splitk - 1) / p.splitk;
   const int it0 = blockIdx.z * per;
   const int it1 = min(nkb, it0 + per);
@@ -25,7 +39,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   f32x4 acc[TM][TN];
   zero_acc(acc);
   RowIdent arm{p.M}, brm{p.N};
-  mainloop<T, BM, BN, WM, WN, CH>(acc, p.seg, m0, p.M, n0, p.N, arm, brm, it0, it1, smem);
+  mainloop<T, BM, BN, WM, WN, CH, AKC, BKC>(acc, p.seg, m0, p.M, n0, p.N, arm, brm, it0, it1, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -44,43 +58,91 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * (TM * 16) + tm * 16 + (lane >> 4) * 4 + r;
-        if (row >= p.M) continue;
-        float v = acc[tm][tn][r] + add;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.C) {
-          float* c = p.C + (int64_t)row * p.ldc + col;
-          if (p.mode == 0)
-            *c = v;
-          else if (p.mode == 1)
-            *c += v;
-          else
-            atomicAdd(c, v);
-        }
-        if (p.Clp) p.Clp[(int64_t)row * p.ldclp + col] = f2bf(v);
+        if (row < p.M) gemm_store(p, row, col, acc[tm][tn][r] + add);
       }
     }
+}
+
+// Scalar fallback for shapes that break the 16-byte staging preconditions (odd K / leading dimension /
+// unaligned views: tiny test shapes and the F=6 toy models).  One thread per output element.
+template <typename T>
+__global__ void gemm_slow_kernel(GemmParams p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)p.M * p.N) return;
+  const int row = (int)(i / p.N), col = (int)(i % p.N);
+  float acc = 0.f;
+  for (int si = 0; si < 2; ++si) {
+    const Seg& s = p.seg[si];
+    const T* A = (const T*)s.A;
+    const T* B = (const T*)s.B;
+    const int64_t ar = s.a_rmod > 0 ? row % s.a_rmod : row;
+    for (int k = 0; k < s.K; ++k) {
+      const T a = s.a_kc ? A[ar * s.lda + k] : A[(int64_t)k * s.lda + ar];
+      const T b = s.b_kc ? B[(int64_t)col * s.ldb + k] : B[(int64_t)k * s.ldb + col];
+      if constexpr (sizeof(T) == 4)
+        acc = fmaf(a, b, acc);
+      else
+        acc = fmaf(bf2f(a), bf2f(b), acc);
+    }
+  }
+  if (p.bias) acc += p.bias[col];
+  if (p.bias2) acc += p.bias2[col];
+  gemm_store(p, row, col, acc);
+}
+
+template <typename T, int CH>
+static void launch_fast(const GemmParams& p, dim3 grid, hipStream_t st) {
+  const int akc = p.seg[0].K > 0 ? p.seg[0].a_kc : p.seg[1].a_kc;
+  const int bkc = p.seg[0].K > 0 ? p.seg[0].b_kc : p.seg[1].b_kc;
+  if (akc && bkc)
+    hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, CH, true, true>), grid, dim3(kThreads), 0, st, p);
+  else if (!akc && !bkc)
+    hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, CH, false, false>), grid, dim3(kThreads), 0, st, p);
+  else if constexpr (sizeof(T) == 4) {
+    if (akc)
+      hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, CH, true, false>), grid, dim3(kThreads), 0, st, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, CH, false, true>), grid, dim3(kThreads), 0, st, p);
+  }
 }
 
 int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
   GemmParams p = p_in;
   if (p.M <= 0 || p.N <= 0) return FHVAE_ERR_SHAPE;
+  if (dtype != FHVAE_F32 && dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
   if (p.splitk < 1) p.splitk = 1;
+  // both segments must share the operand orientation (true for every caller)
+  if (p.seg[0].K > 0 && p.seg[1].K > 0 && (p.seg[0].a_kc != p.seg[1].a_kc || p.seg[0].b_kc != p.seg[1].b_kc))
+    return FHVAE_ERR_SHAPE;
+  const bool bf = dtype == FHVAE_BF16;
+  bool fast = bf ? (seg_fast_ok<u16>(p.seg[0], p.M, p.N) && seg_fast_ok<u16>(p.seg[1], p.M, p.N))
+                 : (seg_fast_ok<float>(p.seg[0], p.M, p.N) && seg_fast_ok<float>(p.seg[1], p.M, p.N));
+  if (bf)
+    for (int s = 0; s < 2; ++s)
+      if (p.seg[s].K > 0 && p.seg[s].a_kc != p.seg[s].b_kc) fast = false;  // bf16 engine: KC/KC or KM/KM only
+  if (!fast) {
+    if (p.splitk > 1) {  // the fallback does not split: same semantics with one slice
+      p.splitk = 1;
+    }
+    const int64_t n = (int64_t)p.M * p.N;
+    if (bf)
+      hipLaunchKernelGGL(gemm_slow_kernel<u16>, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL(gemm_slow_kernel<float>, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, p);
+    return fh_launch_status();
+  }
   dim3 grid((unsigned)fh_cdiv(p.N, 64), (unsigned)fh_cdiv(p.M, 64), (unsigned)p.splitk);
   const int kmax = p.seg[0].K > p.seg[1].K ? p.seg[0].K : p.seg[1].K;
-  if (dtype == FHVAE_F32) {
+  if (!bf) {
     if (kmax <= 64)  // short contraction: 128-byte panels
-      hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 2, 2, 8>), grid, dim3(kThreads), 0, st, p);
+      launch_fast<float, 8>(p, grid, st);
     else
-      hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 2, 2, 32>), grid, dim3(kThreads), 0, st, p);
-  } else if (dtype == FHVAE_BF16) {
-    for (int s = 0; s < 2; ++s)
-      if (p.seg[s].K > 0 && (p.seg[s].a_kc != p.seg[s].b_kc)) return FHVAE_ERR_DTYPE;  // bf16: KC/KC or KM/KM
-    if (kmax <= 128)
-      hipLaunchKernelGGL((gemm_kernel<u16, 64, 64, 2, 2, 8>), grid, dim3(kThreads), 0, st, p);
-    else
-      hipLaunchKernelGGL((gemm_kernel<u16, 64, 64, 2, 2, 32>), grid, dim3(kThreads), 0, st, p);
+      launch_fast<float, 32>(p, grid, st);
   } else {
-    return FHVAE_ERR_DTYPE;
+    if (kmax <= 128)
+      launch_fast<u16, 8>(p, grid, st);
+    else
+      launch_fast<u16, 32>(p, grid, st);
   }
   return fh_launch_status();
 }

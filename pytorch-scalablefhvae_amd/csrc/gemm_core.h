@@ -69,64 +69,48 @@ constexpr int tile_bytes() {
   return kc > km ? kc : km;
 }
 
-template <typename T>
-__device__ __forceinline__ uint4 load_elems(const T* p, int nvalid) {
-  // slow path: up to EPC elements, zero filled
-  constexpr int EPC = Op<T>::EPC;
-  union {
-    uint4 u;
-    T e[EPC];
-  } r;
-  r.u = make_uint4(0, 0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < EPC; ++i)
-    if (i < nvalid) r.e[i] = p[i];
-  return r.u;
-}
-
-// global -> registers for one operand panel (R rows x CH chunks) starting at contraction index k0
-template <typename T, int R, int CH, class RowMap>
-__device__ __forceinline__ void load_tile(uint4 (&v)[R * CH / kThreads], const void* base_, int64_t ld, int kc,
-                                          bool vec_ok, int x0, int X, int k0, int K, const RowMap& rm, int rmod,
-                                          int tid) {
+// global -> registers for one operand panel (R rows x CH chunks) starting at contraction index k0.
+// Preconditions (checked on the host, see seg_fast_ok): base 16-byte aligned, ld % EPC == 0 and the chunked
+// extent (K for KC images, the row count X for KM images) a multiple of EPC -> every 16-byte chunk is either
+// fully inside or fully outside, so the loads are UNCONDITIONAL from a clamped address with the result
+// zeroed by a select.  No per-chunk branches: all loads of the panel issue back to back (a branchy version
+// made hipcc wait vmcnt(0) after every single load: 8 serial L2 round trips per panel).  Shapes that break
+// the preconditions go to the scalar fallback kernel in gemm.hip.
+template <typename T, int R, int CH, bool KC, class RowMap>
+__device__ __forceinline__ void load_tile(uint4 (&v)[R * CH / kThreads], uint32_t& okbits, const void* base_, int64_t ld,
+                                          int x0, int X, int k0, int K, const RowMap& rm, int rmod, int tid) {
+  // okbits: bit p set <=> chunk p holds real data; the zeroing of the others is applied by store_tile, AFTER the
+  // MFMAs of the current panel (masking here would consume the loads and stall right behind their issue)
+  okbits = 0;
   constexpr int EPC = Op<T>::EPC;
   constexpr int NCH = R * CH / kThreads;
   const T* base = (const T*)base_;
-  if (kc) {
+  if constexpr (KC) {
 #pragma unroll
     for (int p = 0; p < NCH; ++p) {
-      int idx = tid + p * kThreads;
-      int row = idx / CH, ch = idx % CH;
-      int64_t grow = rm(x0 + row);
-      if (rmod > 0 && grow >= 0) grow %= rmod;
-      int k = k0 + ch * EPC;
-      if (grow >= 0 && k < K) {
-        const T* src = base + grow * ld + k;
-        if (vec_ok && k + EPC <= K)
-          v[p] = *(const uint4*)src;
-        else
-          v[p] = load_elems<T>(src, K - k);
-      } else {
-        v[p] = make_uint4(0, 0, 0, 0);
-      }
+      const int idx = tid + p * kThreads;
+      const int row = idx / CH, ch = idx % CH;
+      const int64_t grow0 = rm(x0 + row);
+      const int k = k0 + ch * EPC;
+      const bool ok = grow0 >= 0 && k < K;
+      uint32_t g32 = ok ? (uint32_t)grow0 : 0u;  // physical rows are < 2^31 (host-checked)
+      if (rmod > 0) g32 %= (uint32_t)rmod;
+      const int64_t off = ok ? (int64_t)g32 * ld + k : 0;
+      v[p] = *(const uint4*)(base + off);
+      okbits |= ok ? (1u << p) : 0u;
     }
   } else {
     // KM image: CH*EPC k-rows of R elements
     constexpr int CPR = R / EPC;  // 16-byte chunks per k-row
 #pragma unroll
     for (int p = 0; p < NCH; ++p) {
-      int idx = tid + p * kThreads;
-      int krow = idx / CPR, cx = idx % CPR;
-      int k = k0 + krow, x = x0 + cx * EPC;
-      if (k < K && x < X) {
-        const T* src = base + (int64_t)k * ld + x;
-        if (vec_ok && x + EPC <= X)
-          v[p] = *(const uint4*)src;
-        else
-          v[p] = load_elems<T>(src, X - x);
-      } else {
-        v[p] = make_uint4(0, 0, 0, 0);
-      }
+      const int idx = tid + p * kThreads;
+      const int krow = idx / CPR, cx = idx % CPR;
+      const int k = k0 + krow, x = x0 + cx * EPC;
+      const bool ok = k < K && x < X;
+      const int64_t off = ok ? (int64_t)k * ld + x : 0;
+      v[p] = *(const uint4*)(base + off);
+      okbits |= ok ? (1u << p) : 0u;
     }
   }
 }
@@ -137,15 +121,24 @@ __device__ __forceinline__ int kc_off(int row, int ch) {
   return row * (CH * 16) + ((ch ^ (row & SW)) << 4);
 }
 
-template <typename T, int R, int CH>
-__device__ __forceinline__ void store_tile(const uint4 (&v)[R * CH / kThreads], char* lds, int kc, int tid) {
+__device__ __forceinline__ uint4 mask4(uint4 t, uint32_t okbits, int p) {
+  const uint32_t msk = 0u - ((okbits >> p) & 1u);  // all ones / all zeros (a select between objects made hipcc spill)
+  t.x &= msk;
+  t.y &= msk;
+  t.z &= msk;
+  t.w &= msk;
+  return t;
+}
+
+template <typename T, int R, int CH, bool KC>
+__device__ __forceinline__ void store_tile(const uint4 (&v)[R * CH / kThreads], uint32_t okbits, char* lds, int tid) {
   constexpr int EPC = Op<T>::EPC;
   constexpr int NCH = R * CH / kThreads;
-  if (kc) {
+  if constexpr (KC) {
 #pragma unroll
     for (int p = 0; p < NCH; ++p) {
       int idx = tid + p * kThreads;
-      *(uint4*)(lds + kc_off<CH>(idx / CH, idx % CH)) = v[p];
+      *(uint4*)(lds + kc_off<CH>(idx / CH, idx % CH)) = mask4(v[p], okbits, p);
     }
   } else {
     constexpr int CPR = R / EPC;
@@ -154,7 +147,7 @@ __device__ __forceinline__ void store_tile(const uint4 (&v)[R * CH / kThreads], 
     for (int p = 0; p < NCH; ++p) {
       int idx = tid + p * kThreads;
       int krow = idx / CPR, cx = idx % CPR;
-      *(uint4*)(lds + (krow * LD + cx * EPC) * (int)sizeof(T)) = v[p];
+      *(uint4*)(lds + (krow * LD + cx * EPC) * (int)sizeof(T)) = mask4(v[p], okbits, p);
     }
   }
 }
@@ -197,9 +190,19 @@ __device__ __forceinline__ bf16x8 frag_km_bf16(const char* lds, int col0, int j,
   return u.v;
 }
 
+// host-side precondition of the branch-free staging for one segment
+template <typename T>
+__host__ inline bool seg_fast_ok(const Seg& s, int M, int N) {
+  constexpr int EPC = Op<T>::EPC;
+  if (s.K <= 0) return true;
+  auto ok = [&](const void* p, int64_t ld, int ext) { return (((uintptr_t)p) & 15) == 0 && (ld % EPC) == 0 && (ext % EPC) == 0; };
+  return ok(s.A, s.lda, s.a_kc ? s.K : M) && ok(s.B, s.ldb, s.b_kc ? s.K : N);
+}
+
 // The main loop.  Panels of both segments are numbered consecutively; [it_begin, it_end) selects a
-// sub-range (split-K).  smem must hold Tile::SMEM bytes (16-byte aligned).
-template <typename T, int BM, int BN, int WM, int WN, int CH, class ARowMap, class BRowMap>
+// sub-range (split-K).  smem must hold Tile::SMEM bytes (16-byte aligned).  AKC/BKC: operand orientation
+// (compile time; both segments share it).  bf16 supports KC/KC and KM/KM only.
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, class ARowMap, class BRowMap>
 __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const Seg (&segs)[2], int m0, int M,
                                          int n0, int N, const ARowMap& arm, const BRowMap& brm, int it_begin,
                                          int it_end, char* smem) {
@@ -208,6 +211,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
   constexpr int BK = TL::BK;
   constexpr int EPC = Op<T>::EPC;
   constexpr int KSTEP = 4 * EPC;  // contraction elements per j-block (16 for f32, 32 for bf16)
+  static_assert(sizeof(T) == 4 || AKC == BKC, "bf16: KC/KC or KM/KM");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -218,6 +222,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
   const int nkb0 = (segs[0].K + BK - 1) / BK;
 
   uint4 ra[BM * CH / kThreads], rb[BN * CH / kThreads];
+  uint32_t oka = 0, okb = 0;
 
   auto seg_of = [&](int it, int& k0) -> int {
     if (it < nkb0) {
@@ -227,23 +232,21 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
     k0 = (it - nkb0) * BK;
     return 1;
   };
-  auto vec_ok = [&](const void* p, int64_t ld) -> bool { return (((uintptr_t)p) & 15) == 0 && (ld % EPC) == 0; };
   auto issue = [&](int it) {
     int k0;
     const Seg& s = segs[seg_of(it, k0)];
-    load_tile<T, BM, CH>(ra, s.A, s.lda, s.a_kc, vec_ok(s.A, s.lda), m0, M, k0, s.K, arm, s.a_rmod, tid);
-    load_tile<T, BN, CH>(rb, s.B, s.ldb, s.b_kc, vec_ok(s.B, s.ldb), n0, N, k0, s.K, brm, 0, tid);
+    load_tile<T, BM, CH, AKC>(ra, oka, s.A, s.lda, m0, M, k0, s.K, arm, s.a_rmod, tid);
+    load_tile<T, BN, CH, BKC>(rb, okb, s.B, s.ldb, n0, N, k0, s.K, brm, 0, tid);
   };
 
   if (it_begin < it_end) issue(it_begin);
   for (int it = it_begin; it < it_end; ++it) {
     int k0;
     const int si = seg_of(it, k0);
-    const int a_kc = segs[si].a_kc, b_kc = segs[si].b_kc;
     const int kleft = segs[si].K - k0;
     const int nj = kleft >= BK ? CH / 4 : (kleft + KSTEP - 1) / KSTEP;  // j-blocks that hold data
-    store_tile<T, BM, CH>(ra, As, a_kc, tid);
-    store_tile<T, BN, CH>(rb, Bs, b_kc, tid);
+    store_tile<T, BM, CH, AKC>(ra, oka, As, tid);
+    store_tile<T, BN, CH, BKC>(rb, okb, Bs, tid);
     __syncthreads();
     if (it + 1 < it_end) issue(it + 1);  // next panel's loads fly under this panel's MFMAs
 #pragma unroll 2
@@ -253,7 +256,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
           const int row = wm * (TM * 16) + tm * 16 + r;
-          if (a_kc) {
+          if constexpr (AKC) {
             uint4 u = *(const uint4*)(As + kc_off<CH>(row, (j << 2) | q));
             a[tm][0] = __uint_as_float(u.x);
             a[tm][1] = __uint_as_float(u.y);
@@ -268,7 +271,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
           const int row = wn * (TN * 16) + tn * 16 + r;
-          if (b_kc) {
+          if constexpr (BKC) {
             uint4 u = *(const uint4*)(Bs + kc_off<CH>(row, (j << 2) | q));
             b[tn][0] = __uint_as_float(u.x);
             b[tn][1] = __uint_as_float(u.y);
@@ -289,7 +292,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
               acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
       } else {
         bf16x8 a[TM], b[TN];
-        if (a_kc) {  // both KC (launcher guarantees a_kc == b_kc for bf16)
+        if constexpr (AKC) {
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm) {
             uint4 u = *(const uint4*)(As + kc_off<CH>(wm * (TM * 16) + tm * 16 + r, (j << 2) | q));

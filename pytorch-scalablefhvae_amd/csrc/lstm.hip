@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
   RowIdent arm{B};
   GateRowMap brm{H};
   const int nkb = num_kblocks<T, kCH>(J.seg);
-  mainloop<T, BM, BN, WM, WN, kCH>(acc, J.seg, m0, B, n0, (int)gridDim.x * 64, arm, brm, 0, nkb, smem);
+  mainloop<T, BM, BN, WM, WN, kCH, true, true>(acc, J.seg, m0, B, n0, (int)gridDim.x * 64, arm, brm, 0, nkb, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int unit = blockIdx.x * 16 + (lane & 15);
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
   zero_acc(acc);
   RowIdent arm{B}, brm{H};
   const int nkb = num_kblocks<T, kCH>(J.seg);
-  mainloop<T, BM, BN, WM, WN, kCH>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
+  // f32: W is the untransposed master weight (KM operand); bf16: the transposed bf16 copy (KC operand)
+  mainloop<T, BM, BN, WM, WN, kCH, true, sizeof(T) == 2>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -237,13 +238,17 @@ static int check_desc(const fhvae_lstm_desc* d) {
   FH_CHECK_PTR(d->cs);
   FH_CHECK_PTR(d->gates);
   FH_CHECK_PTR(d->pre);
+  // the step cells stage h / W rows in 16-byte chunks: H must be a multiple of 4 (f32) / 8 (bf16)
   if (d->dtype == FHVAE_BF16) {
     FH_CHECK_PTR(d->lp);
-    // bf16 rows are read in 16-byte chunks: every leading dimension must be a multiple of 8
-    if (d->H % 8 || (d->I + d->Ic) % 8 || d->I % 8) return FHVAE_ERR_ALIGN;
-  } else if (d->hs_top_f32) {
-    return FHVAE_ERR_SHAPE;
+    if (d->H % 8) return FHVAE_ERR_ALIGN;
+  } else {
+    if (d->H % 4) return FHVAE_ERR_ALIGN;
+    if (d->hs_top_f32) return FHVAE_ERR_SHAPE;
   }
+  if ((((uintptr_t)d->hs) | ((uintptr_t)d->cs) | ((uintptr_t)d->gates)) & 15) return FHVAE_ERR_ALIGN;
+  for (int l = 0; l < d->L; ++l)
+    if ((((uintptr_t)d->w_ih[l]) | ((uintptr_t)d->w_hh[l])) & 15) return FHVAE_ERR_ALIGN;
   return FHVAE_OK;
 }
 
