@@ -97,10 +97,10 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
       pa[g] = acc[0][g][r] + badd[g];
       if (J.pre) pa[g] += J.pre[(int64_t)row * J.pre_ld + g * H + unit];
     }
-    const float ig = sigmoidf_(pa[0]), fg = sigmoidf_(pa[1]), gg = tanhf(pa[2]), og = sigmoidf_(pa[3]);
+    const float ig = sigmoidf_(pa[0]), fg = sigmoidf_(pa[1]), gg = tanhf_(pa[2]), og = sigmoidf_(pa[3]);
     const float cp = J.c_prev ? J.c_prev[(int64_t)row * H + unit] : 0.f;
     const float c = fg * cp + ig * gg;
-    const float h = og * tanhf(c);
+    const float h = og * tanhf_(c);
     J.c_out[(int64_t)row * H + unit] = c;
     store_h<T>(J.h_out + (int64_t)row * H + unit, h);
     if (J.h_out_f32) J.h_out_f32[(int64_t)row * H + unit] = h;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
     const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
     const int64_t o = (int64_t)row * H + unit;
     const float cp = J.c_prev ? J.c_prev[o] : 0.f;
-    const float tc = tanhf(J.c_cur[o]);
+    const float tc = tanhf_(J.c_cur[o]);
     float dc = dh * og * (1.f - tc * tc);
     if (!J.first) dc += J.dc[o];
     const float d_o = dh * tc;
