@@ -76,30 +76,36 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
   zero_acc(acc);
   RowIdent arm{B};
   GateRowMap brm{H};
+  // epilogue operands are fetched BEFORE the contraction so their latency hides under it
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 16 + (lane & 15);
+  const bool uok = unit < H;
+  float padd[4][4];  // [row r][gate]: pre-activation additive term (input projection or biases)
+  float cprev[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + wave * 16 + (lane >> 4) * 4 + r;
+    const bool ok = uok && row < B;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = 0.f;
+      if (ok && J.pre) v = J.pre[(int64_t)row * J.pre_ld + g * H + unit];
+      if (ok && J.bias_a) v += J.bias_a[g * H + unit] + J.bias_b[g * H + unit];
+      padd[r][g] = v;
+    }
+    cprev[r] = (ok && J.c_prev) ? J.c_prev[(int64_t)row * H + unit] : 0.f;
+  }
   const int nkb = num_kblocks<T, kCH>(J.seg);
   mainloop<T, BM, BN, WM, WN, kCH, true, true>(acc, J.seg, m0, B, n0, (int)gridDim.x * 64, arm, brm, 0, nkb, smem);
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 16 + (lane & 15);
-  if (unit >= H) return;
-  float badd[4] = {0.f, 0.f, 0.f, 0.f};
-  if (J.bias_a) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) badd[g] = J.bias_a[g * H + unit] + J.bias_b[g * H + unit];
-  }
+  if (!uok) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = m0 + wave * 16 + (lane >> 4) * 4 + r;
     if (row >= B) continue;
-    float pa[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      pa[g] = acc[0][g][r] + badd[g];
-      if (J.pre) pa[g] += J.pre[(int64_t)row * J.pre_ld + g * H + unit];
-    }
-    const float ig = sigmoidf_(pa[0]), fg = sigmoidf_(pa[1]), gg = tanhf_(pa[2]), og = sigmoidf_(pa[3]);
-    const float cp = J.c_prev ? J.c_prev[(int64_t)row * H + unit] : 0.f;
-    const float c = fg * cp + ig * gg;
+    const float ig = sigmoidf_(acc[0][0][r] + padd[r][0]), fg = sigmoidf_(acc[0][1][r] + padd[r][1]);
+    const float gg = tanhf_(acc[0][2][r] + padd[r][2]), og = sigmoidf_(acc[0][3][r] + padd[r][3]);
+    const float c = fg * cprev[r] + ig * gg;
     const float h = og * tanhf_(c);
     J.c_out[(int64_t)row * H + unit] = c;
     store_h<T>(J.h_out + (int64_t)row * H + unit, h);
@@ -149,30 +155,43 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
   f32x4 acc[1][1];
   zero_acc(acc);
   RowIdent arm{B}, brm{H};
+  // epilogue operands first: their latency hides under the contraction
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int unit = n0 + wn * 16 + (lane & 15);
+  const bool uok = unit < H;
+  float e_ext[4], e_g[4][4], e_cp[4], e_cc[4], e_dc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + wm * 16 + (lane >> 4) * 4 + r;
+    const bool ok = uok && row < B;
+    const int64_t o = (int64_t)row * H + unit;
+    float ex = 0.f;
+    if (ok && J.ext) ex = J.ext[(int64_t)row * J.ext_ld + unit];
+    if (ok && J.ext2) ex += J.ext2[(int64_t)row * J.ext2_ld + unit];
+    e_ext[r] = ex;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_g[r][g] = ok ? J.gates[(int64_t)row * 4 * H + g * H + unit] : 0.f;
+    e_cp[r] = (ok && J.c_prev) ? J.c_prev[o] : 0.f;
+    e_cc[r] = ok ? J.c_cur[o] : 0.f;
+    e_dc[r] = (ok && !J.first) ? J.dc[o] : 0.f;
+  }
   const int nkb = num_kblocks<T, kCH>(J.seg);
   // f32: W is the untransposed master weight (KM operand); bf16: the transposed bf16 copy (KC operand)
   mainloop<T, BM, BN, WM, WN, kCH, true, sizeof(T) == 2>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int unit = n0 + wn * 16 + (lane & 15);
-  if (unit >= H) return;
+  if (!uok) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = m0 + wm * 16 + (lane >> 4) * 4 + r;
     if (row >= B) continue;
-    float dh = acc[0][0][r];
-    if (J.ext) dh += J.ext[(int64_t)row * J.ext_ld + unit];
-    if (J.ext2) dh += J.ext2[(int64_t)row * J.ext2_ld + unit];
-    const float* gp = J.gates + (int64_t)row * 4 * H + unit;
-    const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+    const float dh = acc[0][0][r] + e_ext[r];
+    const float ig = e_g[r][0], fg = e_g[r][1], gg = e_g[r][2], og = e_g[r][3];
     const int64_t o = (int64_t)row * H + unit;
-    const float cp = J.c_prev ? J.c_prev[o] : 0.f;
-    const float tc = tanhf_(J.c_cur[o]);
-    float dc = dh * og * (1.f - tc * tc);
-    if (!J.first) dc += J.dc[o];
+    const float tc = tanhf_(e_cc[r]);
+    const float dc = dh * og * (1.f - tc * tc) + e_dc[r];
     const float d_o = dh * tc;
-    const float d_i = dc * gg, d_f = dc * cp, d_g = dc * ig;
+    const float d_i = dc * gg, d_f = dc * e_cp[r], d_g = dc * ig;
     J.dc[o] = dc * fg;
     float dp[4];
     dp[0] = d_i * ig * (1.f - ig);
