@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="MFMA operand type of the LSTM nets (configs[1] is quoted in bf16; f32 = exact-f32 parity mode)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel eagerly instead of replaying the captured hipGraph of the whole step")
     ap.add_argument("--force-dist", action="store_true", help="use the distributed runner even with one rank (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -148,6 +150,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The whole step (zero_grad, forward, loss, backward, collectives excluded, Adam) is ~400 short launches:
+    # capture it once into a hipGraph and replay (single-GPU path; the distributed runner stays eager because
+    # RCCL collectives are enqueued from the host between the phases).
+    use_graph = not args.no_graph and runner is None
+    eager_step = step
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_loss, g_lb = eager_step()
+
+        def step():
+            graph.replay()
+            return g_loss, g_lb
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -170,7 +193,7 @@ def main():
         # instrumented pass: HIP events (torch's current stream == the launch stream) around every C-ABI call
         hb.OP_TIMER.enable()
         for _ in range(args.steps):
-            step()
+            eager_step()
         torch.cuda.synchronize()
         per_op = hb.OP_TIMER.summary()
         hb.OP_TIMER.disable()
@@ -192,6 +215,7 @@ def main():
             "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic", "elbo_nats_per_frame": elbo, "loss_finite": ok,
+            "launch": "hipGraph replay of the whole step" if use_graph else "eager",
             "config": {"workload": "%s: %s; per-GPU batch %d, T=%d, F=%d, full train step (fwd+loss+bwd+Adam), "
                                    "intended objective" % (args.config, cfg["desc"], B, T, F),
                        "global_batch": world * B, "parallelism": "dp%d+mu2-row-shard" % world if use_dist else "single"},

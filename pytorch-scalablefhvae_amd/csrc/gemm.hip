@@ -170,25 +170,55 @@ __global__ void relu_mask_kernel(const float* __restrict__ dy, int64_t lddy, con
   out[i] = y[m * ldy + n] > 0.f ? dy[m * lddy + n] : 0.f;
 }
 
-// db[n] += sum_m g[m][n] : 64 columns x 4 row lanes per block, rows strided over gridDim.y
+// db[n] += sum_m g[m][n].  Thread = one 16-byte column group (4 f32 / 8 bf16) x one of 8 row lanes; a block
+// covers 32 column groups; rows are strided over gridDim.y; 8 row lanes reduce through LDS, then atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, int64_t ldg, float* __restrict__ db,
                                                      float* __restrict__ db2, int64_t M, int64_t N) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 64 + c;
-  float s = 0.f;
-  if (n < N)
-    for (int64_t m = (int64_t)blockIdx.y * 4 + rg; m < M; m += (int64_t)gridDim.y * 4) {
-      if constexpr (sizeof(T) == 4)
-        s += g[m * ldg + n];
-      else
-        s += bf2f(g[m * ldg + n]);
+  constexpr int E = 16 / (int)sizeof(T);
+  __shared__ float red[8][32 * E + 1];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int64_t n0 = ((int64_t)blockIdx.x * 32 + cg) * E;
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  const bool vec = (ldg % E == 0) && ((((uintptr_t)g) & 15) == 0) && n0 + E <= N;
+  for (int64_t m = (int64_t)blockIdx.y * 8 + rl; m < M; m += (int64_t)gridDim.y * 8) {
+    if (vec) {
+      const uint4 u = *(const uint4*)(g + m * ldg + n0);
+      if constexpr (sizeof(T) == 4) {
+        s[0] += __uint_as_float(u.x);
+        s[1] += __uint_as_float(u.y);
+        s[2] += __uint_as_float(u.z);
+        s[3] += __uint_as_float(u.w);
+      } else {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[2 * e] += __uint_as_float(w[e] << 16);
+          s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (n0 + e < N) {
+          if constexpr (sizeof(T) == 4)
+            s[e] += g[m * ldg + n0 + e];
+          else
+            s[e] += bf2f(g[m * ldg + n0 + e]);
+        }
     }
-  red[rg][c] = s;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) red[rl][cg * E + e] = s[e];
   __syncthreads();
-  if (rg == 0 && n < N) {
-    float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  for (int c = threadIdx.x; c < 32 * E; c += 256) {
+    const int64_t n = (int64_t)blockIdx.x * 32 * E + c;
+    if (n >= N) continue;
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][c];
     if (db) atomicAdd(db + n, t);
     if (db2) atomicAdd(db2 + n, t);
   }
@@ -196,10 +226,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, in
 
 int launch_colsum(const void* g, int dtype, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st) {
   if (!db && !db2) return FHVAE_OK;
-  int64_t gy = fh_cdiv(M, 4 * 16);
-  if (gy > 64) gy = 64;
+  const int E = dtype == FHVAE_F32 ? 4 : 8;
+  int64_t gx = fh_cdiv(N, 32 * E);
+  int64_t gy = fh_cdiv(M, 8 * 8);
+  const int64_t want = fh_cdiv(1024, gx);
+  if (gy > want) gy = want;
   if (gy < 1) gy = 1;
-  dim3 grid((unsigned)fh_cdiv(N, 64), (unsigned)gy);
+  dim3 grid((unsigned)gx, (unsigned)gy);
   if (dtype == FHVAE_F32)
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)g, ldg, db, db2, M, N);
   else

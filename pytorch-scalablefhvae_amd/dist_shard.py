@@ -89,6 +89,7 @@ class _ShardGather(torch.autograd.Function):
     def forward(ctx, shard, idx_all, sh: ShardCtx):
         rows_all = sh.backend.gather_rows(shard, idx_all, sh.row0)  # zeros for rows owned elsewhere
         ctx.sh, ctx.shape = sh, tuple(shard.shape)
+        ctx.sink = getattr(shard, "_fh_grad", None)
         ctx.save_for_backward(idx_all)
         return sh.reduce_scatter(rows_all)
 
@@ -97,10 +98,11 @@ class _ShardGather(torch.autograd.Function):
         sh = ctx.sh
         (idx_all,) = ctx.saved_tensors
         d_all = sh.all_gather(dmu2.contiguous())
-        dshard = torch.zeros(ctx.shape, device=dmu2.device, dtype=dmu2.dtype)
+        sink = ctx.sink
+        dshard = sink if sink is not None else torch.zeros(ctx.shape, device=dmu2.device, dtype=dmu2.dtype)
         # the objective is the mean over ranks of the local losses: 1/W on every rank's contribution
         sh.backend.scatter_rows_(dshard, d_all, idx_all, sh.row0, 1.0 / sh.world)
-        return dshard, None, None
+        return (None if sink is not None else dshard), None, None
 
 
 class _ShardDisc(torch.autograd.Function):

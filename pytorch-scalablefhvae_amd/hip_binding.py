@@ -195,6 +195,13 @@ def _need_gpu(*ts):
             )
 
 
+def _sink(t):
+    """Gradient sink of a parameter: hip_optim.FusedAdam registers `param._fh_grad` (a view of its flat
+    gradient arena).  Backward kernels then ACCUMULATE straight into it and the Function returns None for
+    that input: no zero-filled temporary, no `param.grad += g` pass per parameter per step."""
+    return getattr(t, "_fh_grad", None) if t is not None else None
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise RuntimeError("fhvae HIP ops take float32 tensors (got %s)" % t.dtype)
@@ -215,7 +222,8 @@ def raw_linear_fwd(x, w, b, relu=False):
     return y
 
 
-def raw_linear_bwd(x, w, y, dy, relu, need_dx=True, need_dw=True, need_db=True, dx_out=None):
+def raw_linear_bwd(x, w, y, dy, relu, need_dx=True, need_dw=True, need_db=True, dx_out=None, dw_sink=None, db_sink=None):
+    """dw_sink / db_sink: existing buffers to accumulate into (returned dw / db are then None)."""
     lib = load_library()
     M, K = x.shape
     N = w.shape[0]
@@ -223,8 +231,8 @@ def raw_linear_bwd(x, w, y, dy, relu, need_dx=True, need_dw=True, need_db=True, 
     masked = torch.empty(M, N, device=dev, dtype=torch.float32) if relu else None
     acc = dx_out is not None
     dx = dx_out if acc else (torch.empty(M, K, device=dev, dtype=torch.float32) if need_dx else None)
-    dw = torch.zeros(N, K, device=dev, dtype=torch.float32) if need_dw else None
-    db = torch.zeros(N, device=dev, dtype=torch.float32) if need_db else None
+    dw = dw_sink if dw_sink is not None else (torch.zeros(N, K, device=dev, dtype=torch.float32) if need_dw else None)
+    db = db_sink if db_sink is not None else (torch.zeros(N, device=dev, dtype=torch.float32) if need_db else None)
     with _Timed("fhvae_linear_bwd"):
         _check(lib.fhvae_linear_bwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(y), N if y is not None else 0, _p(dy),
                                     dy.stride(0), _p(masked), _p(dx), K, _p(dw), K, _p(db), M, K, N, int(relu), int(acc),
@@ -241,6 +249,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, relu):
         _need_gpu(x, w, b)
+        ctx.sinks = (_sink(w), _sink(b))
         x, w, b = _f32c(x), _f32c(w), _f32c(b)
         y = raw_linear_fwd(x, w, b, relu)
         ctx.relu = relu
@@ -252,7 +261,8 @@ class _Linear(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         dy = _f32c(dy)
         dx, dw, db = raw_linear_bwd(x, w, y, dy, ctx.relu, need_dx=ctx.needs_input_grad[0],
-                                    need_dw=ctx.needs_input_grad[1], need_db=ctx.needs_input_grad[2])
+                                    need_dw=ctx.needs_input_grad[1], need_db=ctx.needs_input_grad[2],
+                                    dw_sink=ctx.sinks[0], db_sink=ctx.sinks[1])
         return dx, dw, db, None
 
 
@@ -267,6 +277,7 @@ class _GaussHead(torch.autograd.Function):
     def forward(ctx, h, w_mu, b_mu, w_lv, b_lv, eps):
         _need_gpu(h, w_mu, b_mu, w_lv, b_lv, eps)
         lib = load_library()
+        ctx.sinks = tuple(_sink(t) for t in (w_mu, b_mu, w_lv, b_lv))
         h, w_mu, b_mu, w_lv, b_lv = _f32c(h), _f32c(w_mu), _f32c(b_mu), _f32c(w_lv), _f32c(b_lv)
         M, K = h.shape
         D = w_mu.shape[0]
@@ -302,8 +313,10 @@ class _GaussHead(torch.autograd.Function):
             _check(lib.fhvae_gauss_reparam_bwd(_p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), _p(g_mu), _p(g_lv), M * D, _stream()),
                    "fhvae_gauss_reparam_bwd")
         need_dh = ctx.needs_input_grad[0]
-        dh, dw_mu, db_mu = raw_linear_bwd(h, w_mu, None, g_mu, False, need_dx=need_dh)
-        _, dw_lv, db_lv = raw_linear_bwd(h, w_lv, None, g_lv, False, need_dx=need_dh, dx_out=dh if need_dh else None)
+        sk = ctx.sinks
+        dh, dw_mu, db_mu = raw_linear_bwd(h, w_mu, None, g_mu, False, need_dx=need_dh, dw_sink=sk[0], db_sink=sk[1])
+        _, dw_lv, db_lv = raw_linear_bwd(h, w_lv, None, g_lv, False, need_dx=need_dh, dx_out=dh if need_dh else None,
+                                         dw_sink=sk[2], db_sink=sk[3])
         return dh, dw_mu, db_mu, dw_lv, db_lv, None
 
 
@@ -343,6 +356,7 @@ class _LstmSeq(torch.autograd.Function):
         _need_gpu(x_tm, xc, *params)
         L = len(params) // 4
         assert len(params) == 4 * L and 1 <= L <= MAX_LAYERS
+        ctx.sinks = [_sink(p) for p in params]
         params = [_f32c(p) for p in params]
         H = params[1].shape[1]
         x_tm = _f32c(x_tm) if x_tm is not None else None
@@ -395,7 +409,7 @@ class _LstmSeq(torch.autograd.Function):
         dgates = torch.empty(L, T, B, 4 * H, device=dev, dtype=hs.dtype)
         dgsum = torch.empty(B, 4 * H, **f32) if Ic > 0 else None
         dc = torch.empty(L, B, H, **f32)
-        grads = [torch.zeros_like(p) for p in params]
+        grads = [sk if sk is not None else torch.zeros_like(p) for p, sk in zip(params, ctx.sinks)]
         d_xc = torch.empty(B, Ic, **f32) if (Ic > 0 and ctx.needs_input_grad[1]) else None
         bd.d_hs_top, bd.d_hn = _p(d_hs_top), _p(d_hn)
         bd.dgates, bd.dgsum, bd.dc = _p(dgates), _p(dgsum), _p(dc)
@@ -404,7 +418,7 @@ class _LstmSeq(torch.autograd.Function):
         bd.d_xc = _p(d_xc)
         with _Timed("fhvae_lstm_seq_bwd"):
             _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
-        return (None, d_xc, None, None, *grads)
+        return (None, d_xc, None, None, *[None if sk is not None else g for g, sk in zip(grads, ctx.sinks)])
 
 
 def lstm_seq(x_tm, xc, T, params: Sequence[torch.Tensor], dtype: int = F32):
@@ -438,6 +452,7 @@ class _Mu2Gather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, idx):
         _need_gpu(table, idx)
+        ctx.sink = _sink(table)
         table = _f32c(table)
         out = raw_gather_rows(table, idx)
         ctx.save_for_backward(idx)
@@ -448,9 +463,9 @@ class _Mu2Gather(torch.autograd.Function):
     def backward(ctx, dmu2):
         (idx,) = ctx.saved_tensors
         dmu2 = _f32c(dmu2)
-        dt = torch.zeros(ctx.shape, device=dmu2.device, dtype=torch.float32)
+        dt = ctx.sink if ctx.sink is not None else torch.zeros(ctx.shape, device=dmu2.device, dtype=torch.float32)
         raw_scatter_rows_(dt, dmu2, idx)
-        return dt, None
+        return (None if ctx.sink is not None else dt), None
 
 
 def mu2_gather(table, idx):
@@ -535,16 +550,16 @@ def raw_disc_fwd(q, table, idx, row0=0, want_ce=True):
     return rmax, rsum, tgt, ce
 
 
-def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True, need_dt=True):
+def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True, need_dt=True, dt_sink=None):
     lib = load_library()
     B, D = q.shape
     S = table.shape[0]
     dq = torch.empty(B, D, device=q.device, dtype=torch.float32) if need_dq else None
-    dt = torch.zeros(S, D, device=q.device, dtype=torch.float32) if need_dt else None
+    dt = dt_sink if dt_sink is not None else (torch.zeros(S, D, device=q.device, dtype=torch.float32) if need_dt else None)
     with _Timed("fhvae_disc_lse_bwd"):
         _check(lib.fhvae_disc_lse_bwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(g_scale), float(g_mul),
                                       _p(dq), _p(dt), None, B, S, D, _stream()), "fhvae_disc_lse_bwd")
-    return dq, dt
+    return dq, (None if dt_sink is not None else dt)
 
 
 def raw_disc_rescale(rmax_local, rsum_local, m_global):
@@ -571,6 +586,7 @@ class _DiscLse(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, table, idx):
         _need_gpu(q, table, idx)
+        ctx.sink = _sink(table)
         q, table = _f32c(q), _f32c(table)
         rmax, rsum, _, ce = raw_disc_fwd(q, table, idx)
         ctx.save_for_backward(q, table, idx, rmax, rsum)
@@ -581,7 +597,7 @@ class _DiscLse(torch.autograd.Function):
         q, table, idx, rmax, rsum = ctx.saved_tensors
         g = _f32c(g).reshape(1)
         dq, dt = raw_disc_bwd(q, table, idx, rmax, rsum, g, 1.0 / q.shape[0], need_dq=ctx.needs_input_grad[0],
-                              need_dt=ctx.needs_input_grad[1])
+                              need_dt=ctx.needs_input_grad[1], dt_sink=ctx.sink)
         return dq, dt, None
 
 

@@ -44,6 +44,7 @@ class FusedAdam(torch.optim.Optimizer):
                 pv.copy_(p.data)
                 p.data = pv          # the parameter now lives in the arena
                 p.grad = gv          # gradients accumulate straight into the flat gradient arena
+                p._fh_grad = gv      # ... and the HIP backward kernels write there directly (hip_binding._sink)
         self.m = torch.zeros_like(self.p_arena.flat)
         self.v = torch.zeros_like(self.p_arena.flat)
         self.step_dev = torch.zeros((), device=params[0].device, dtype=torch.int32)

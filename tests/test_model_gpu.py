@@ -193,3 +193,34 @@ def test_distributed_wrapper_world1_matches_single_gpu(hb):
     for a, b in zip(got, ref_losses):
         assert abs(a - b) <= 1e-4 * abs(b), (got, ref_losses)
     close(runner.shard, m1.mu2_table, rtol=1e-4, what="table after 3 steps")
+
+
+def test_fused_adam_grad_sinks_match_torch_adam(hb):
+    """FusedAdam (flat arena; backward kernels accumulate straight into it) against torch.optim.Adam driving
+    the same HIP model through plain autograd gradients: same parameters after several steps."""
+    from fhvae import FHVAE
+    from hip_optim import FusedAdam
+    from train_model import loss_function
+
+    T, F, H, D, B, S = 20, 80, 32, 16, 40, 29
+    x = torch.randn(B, T, F, generator=torch.Generator().manual_seed(1)).cuda()
+    idx = torch.randint(0, S, (B,), generator=torch.Generator().manual_seed(2))
+    idx[3] = idx[2]
+    ns = torch.randint(20, 200, (B,), generator=torch.Generator().manual_seed(3))
+    eps = (torch.randn(B, D, generator=torch.Generator().manual_seed(4)), torch.randn(B, D, generator=torch.Generator().manual_seed(5)))
+
+    def run(make_opt):
+        torch.manual_seed(11)
+        m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], num_seqs=S, reference_compat=False).cuda()
+        opt = make_opt(m.parameters())
+        for _ in range(4):
+            opt.zero_grad()
+            out = m(x, idx, S, ns, eps=eps)
+            loss_function(out[0], out[1], 10.0).backward()
+            opt.step()
+        return {n: p.detach().clone() for n, p in m.named_parameters()}
+
+    a = run(lambda ps: torch.optim.Adam(ps, lr=1e-3, betas=(0.95, 0.999)))
+    b = run(lambda ps: FusedAdam(ps, lr=1e-3, betas=(0.95, 0.999)))
+    for n in a:
+        close(b[n], a[n], rtol=2e-4, what=n)
