@@ -90,26 +90,38 @@ __global__ void gemm_slow_kernel(GemmParams p) {
   gemm_store(p, row, col, acc);
 }
 
-template <typename T, int CH>
+template <typename T, int BM, int BN, int CH>
 static void launch_fast(const GemmParams& p, dim3 grid, hipStream_t st) {
   const int akc = p.seg[0].K > 0 ? p.seg[0].a_kc : p.seg[1].a_kc;
   const int bkc = p.seg[0].K > 0 ? p.seg[0].b_kc : p.seg[1].b_kc;
   if (akc && bkc)
-    hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, CH, true, true>), grid, dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, true, true>), grid, dim3(kThreads), 0, st, p);
   else if (!akc && !bkc)
-    hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, CH, false, false>), grid, dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, false, false>), grid, dim3(kThreads), 0, st, p);
   else if constexpr (sizeof(T) == 4) {
     if (akc)
-      hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, CH, true, false>), grid, dim3(kThreads), 0, st, p);
+      hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, true, false>), grid, dim3(kThreads), 0, st, p);
     else
-      hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, CH, false, true>), grid, dim3(kThreads), 0, st, p);
+      hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, false, true>), grid, dim3(kThreads), 0, st, p);
   }
+}
+
+// splitk == 0 on entry means "choose": only legal with mode 1 (accumulate), switched to atomics when split
+static int auto_splitk(int64_t tiles, int64_t panels) {
+  if (tiles >= 192 || panels < 4) return 1;
+  int64_t s = fh_cdiv(512, tiles);
+  if (s > panels / 2) s = panels / 2;
+  if (s < 1) s = 1;
+  if (s > 128) s = 128;
+  return (int)s;
 }
 
 int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
   GemmParams p = p_in;
   if (p.M <= 0 || p.N <= 0) return FHVAE_ERR_SHAPE;
   if (dtype != FHVAE_F32 && dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
+  const bool want_auto = p.splitk == 0;
+  if (want_auto && p.mode != 1) return FHVAE_ERR_SHAPE;
   if (p.splitk < 1) p.splitk = 1;
   // both segments must share the operand orientation (true for every caller)
   if (p.seg[0].K > 0 && p.seg[1].K > 0 && (p.seg[0].a_kc != p.seg[1].a_kc || p.seg[0].b_kc != p.seg[1].b_kc))
@@ -121,9 +133,7 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
     for (int s = 0; s < 2; ++s)
       if (p.seg[s].K > 0 && p.seg[s].a_kc != p.seg[s].b_kc) fast = false;  // bf16 engine: KC/KC or KM/KM only
   if (!fast) {
-    if (p.splitk > 1) {  // the fallback does not split: same semantics with one slice
-      p.splitk = 1;
-    }
+    p.splitk = 1;  // the fallback does not split: same semantics with one slice
     const int64_t n = (int64_t)p.M * p.N;
     if (bf)
       hipLaunchKernelGGL(gemm_slow_kernel<u16>, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, p);
@@ -131,32 +141,41 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
       hipLaunchKernelGGL(gemm_slow_kernel<float>, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, p);
     return fh_launch_status();
   }
-  dim3 grid((unsigned)fh_cdiv(p.N, 64), (unsigned)fh_cdiv(p.M, 64), (unsigned)p.splitk);
+  const int ktot = p.seg[0].K + p.seg[1].K;
   const int kmax = p.seg[0].K > p.seg[1].K ? p.seg[0].K : p.seg[1].K;
+  const int epc = bf ? 8 : 4;
+  // 128x128 tiles (half the L2->LDS traffic per FLOP) once the problem offers enough of them
+  // (measured: with fewer than ~2 workgroups per CU the per-CU load bandwidth, not the aggregate L2 traffic,
+  // is the limit, and 64x64 tiles on more CUs win: 2048x1024x512 bf16 takes 11 us with 64^2, 21 us with 128^2)
+  const bool big = kmax > 16 * epc && fh_cdiv(p.M, 128) * fh_cdiv(p.N, 128) >= 512;
+  const int tb = big ? 128 : 64;
+  const int ch = big ? 16 : (kmax <= 16 * epc ? 8 : 32);
+  if (want_auto) {
+    p.splitk = auto_splitk(fh_cdiv(p.M, tb) * fh_cdiv(p.N, tb), fh_cdiv(ktot, ch * epc));
+    if (p.splitk > 1) p.mode = 2;
+  }
+  dim3 grid((unsigned)fh_cdiv(p.N, tb), (unsigned)fh_cdiv(p.M, tb), (unsigned)p.splitk);
   if (!bf) {
-    if (kmax <= 64)  // short contraction: 128-byte panels
-      launch_fast<float, 8>(p, grid, st);
+    if (big)
+      launch_fast<float, 128, 128, 16>(p, grid, st);
+    else if (ch == 8)
+      launch_fast<float, 64, 64, 8>(p, grid, st);
     else
-      launch_fast<float, 32>(p, grid, st);
+      launch_fast<float, 64, 64, 32>(p, grid, st);
   } else {
-    if (kmax <= 128)
-      launch_fast<u16, 8>(p, grid, st);
+    if (big)
+      launch_fast<u16, 128, 128, 16>(p, grid, st);
+    else if (ch == 8)
+      launch_fast<u16, 64, 64, 8>(p, grid, st);
     else
-      launch_fast<u16, 32>(p, grid, st);
+      launch_fast<u16, 64, 64, 32>(p, grid, st);
   }
   return fh_launch_status();
 }
 
-// heuristic split of the contraction for weight-gradient GEMMs (few output tiles, long K)
+// kept for callers that want an explicit split (none at present)
 int pick_splitk(int64_t M, int64_t N, int64_t K) {
-  int64_t tiles = fh_cdiv(M, 64) * fh_cdiv(N, 64);
-  int64_t nkb = fh_cdiv(K, 128);  // panels of the CH = 32 kernels (f32; bf16 panels are 256)
-  if (tiles >= 256 || nkb < 4) return 1;
-  int64_t s = fh_cdiv(512, tiles);
-  if (s > nkb / 2) s = nkb / 2;
-  if (s < 1) s = 1;
-  if (s > 64) s = 64;
-  return (int)s;
+  return auto_splitk(fh_cdiv(M, 64) * fh_cdiv(N, 64), fh_cdiv(K, 128));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -336,8 +355,8 @@ extern "C" int fhvae_linear_bwd(const float* x, int64_t ldx, const float* w, int
     p.N = (int)K;
     p.C = dw;
     p.ldc = lddw;
-    p.splitk = pick_splitk(N, K, M);
-    p.mode = p.splitk > 1 ? 2 : 1;
+    p.splitk = 0;  // auto
+    p.mode = 1;
     int e = launch_gemm(p, FHVAE_F32, st);
     if (e) return e;
   }
