@@ -190,24 +190,42 @@ def main():
 
     roof = None
     if not args.no_roofline and rank == 0:
-        # instrumented pass: HIP events (torch's current stream == the launch stream) around every C-ABI call
+        # Instrumented EAGER repeat of the same steps: (1) HIP events (torch's current stream == the launch stream)
+        # around every C-ABI call, (2) the library's own per-launch event pairs around every LSTM step-cell
+        # launch, each tagged with its algorithmic FLOPs (fhvae_trace_*).  The dominant kernel is the cell kind
+        # with the larger total time; achieved = its algorithmic FLOPs / its summed launch durations.
         hb.OP_TIMER.enable()
+        hb.cell_trace(True)
+        cells = {}
         for _ in range(args.steps):
             eager_step()
+            for k, (n, t, f) in hb.cell_trace_collect().items():
+                c = cells.get(k, (0, 0.0, 0.0))
+                cells[k] = (c[0] + n, c[1] + t, c[2] + f)
         torch.cuda.synchronize()
+        hb.cell_trace(False)
         per_op = hb.OP_TIMER.summary()
         hb.OP_TIMER.disable()
-        lf = lstm_flops_fwd(cfg, B)
-        fwd_ms = per_op.get("fhvae_lstm_seq_fwd", (0, 0.0))[1] / args.steps
-        bwd_ms = per_op.get("fhvae_lstm_seq_bwd", (0, 0.0))[1] / args.steps
-        # dominant op: the LSTM sequence kernels (step cells + their weight-gradient GEMMs); bwd = 2x fwd FLOPs
-        ach = (3 * lf) / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
+        names = {0: "lstm_fwd_step_kernel", 1: "lstm_bwd_step_kernel"}
+        dom = max(cells, key=lambda k: cells[k][1])
+        n, t_ms, fl = cells[dom]
+        ach = fl / (t_ms * 1e-3) / 1e12
         # dense MFMA peaks (MI355X_MICROARCH.md, matrix cores): bf16 ~2500 TFLOP/s, f32-input 157.3 TFLOP/s
         peak = 2500.0 if args.dtype == "bf16" else 157.3
-        roof = {"bound": "mfma", "kernel": "lstm_seq fwd+bwd (lstm_fwd_step_kernel, lstm_bwd_step_kernel, gemm_kernel)",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                "ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_op.items())},
-                "launch_ms": {"lstm_seq_fwd_call": fwd_ms / 3.0, "lstm_seq_bwd_call": bwd_ms / 3.0}}
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):  # HBM bytes per launch from rocprofv3 --pmc passes of this command (tools/pmc_traffic.py)
+            try:
+                traffic = json.load(open(tf)).get("%s_%s_B%d" % (names[dom], args.dtype, B))
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": "%s<%s>" % (names[dom], args.dtype), "achieved": ach, "peak": peak,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                "launches_per_step": n / args.steps, "avg_launch_us": t_ms / n * 1e3,
+                "flops_per_launch": fl / n,
+                "cells": {names[k]: {"launches_per_step": v[0] / args.steps, "avg_launch_us": v[1] / v[0] * 1e3,
+                                     "tflops": v[2] / (v[1] * 1e-3) / 1e12} for k, v in cells.items()},
+                "op_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_op.items())}}
 
     if rank == 0:
         rec = {

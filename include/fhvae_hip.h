@@ -234,6 +234,16 @@ int fhvae_adam_step(float* p, const float* g, float* m, float* v, void* p_lp, in
                     float beta1, float beta2, float eps, float grad_scale, int32_t* step_count,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py roofline leg; no reference counterpart): while enabled, every step-cell launch
+ * of fhvae_lstm_seq_fwd/bwd is bracketed by two HIP events on its stream and tagged with its kind
+ * (0 = forward cell, 1 = backward cell) and its algorithmic FLOPs.  fhvae_trace_collect synchronises on
+ * the recorded events, returns the number of records copied (host arrays, any may be NULL) and clears the
+ * trace.  Off by default; the only process-global state of the library; not for use under graph capture.
+ * ------------------------------------------------------------------------------------------ */
+int fhvae_trace_enable(int on);
+int64_t fhvae_trace_collect(float* ms, int32_t* kind, double* flops, int64_t cap);
+
 /* small utilities used by the host side */
 /* (B,T,F) batch-major f32 -> (T,B,F) time-major in operand dtype `dtype` (and optionally f32) */
 int fhvae_to_time_major(const float* x_btf, void* x_tbf, float* x_tbf_f32, int64_t B, int64_t T,

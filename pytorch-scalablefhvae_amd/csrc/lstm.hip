@@ -14,6 +14,7 @@
 // same (segment, unit)) and applies sigmoid/tanh + the cell update in registers: the (B,4H)
 // pre-activations never touch HBM.
 #include "gemm_launch.h"
+#include "trace.h"
 
 namespace fh {
 
@@ -423,6 +424,9 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
         J.hn_ld = (int64_t)L * H;
       }
     }
+    double fl = 0;
+    for (int j = 0; j < nj; ++j) fl += 2.0 * B * 4 * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
+    const int ts = trace_begin(st, kTraceFwdCell, fl);
     if (B >= 16384) {  // large tiles only pay once they still give >= 2 workgroups per CU (see gemm.hip)
       dim3 grid((unsigned)fh_cdiv(H, 32), (unsigned)fh_cdiv(B, 128), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 128, 128, 2, 2, 16>), grid, dim3(kThreads), 0, st, jobs);
@@ -430,6 +434,7 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
       dim3 grid((unsigned)fh_cdiv(H, 16), (unsigned)fh_cdiv(B, 64), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 64, 64, 4, 1, kCH>), grid, dim3(kThreads), 0, st, jobs);
     }
+    trace_end(st, ts);
     int e = fh_launch_status();
     if (e) return e;
   }
@@ -491,6 +496,9 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
       J.dg_out = dg + lt * B * 4 * H;
       J.dgsum = (l == 0 && Ic > 0) ? bd->dgsum : nullptr;
     }
+    double fl = 0;
+    for (int j = 0; j < nj; ++j) fl += 2.0 * B * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
+    const int ts = trace_begin(st, kTraceBwdCell, fl);
     if (B >= 16384) {
       dim3 grid((unsigned)fh_cdiv(H, 64), (unsigned)fh_cdiv(B, 128), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 128, 64, 4, 1, 16>), grid, dim3(kThreads), 0, st, jobs);
@@ -498,6 +506,7 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
       dim3 grid((unsigned)fh_cdiv(H, 32), (unsigned)fh_cdiv(B, 32), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 32, 32, 2, 2, kCH>), grid, dim3(kThreads), 0, st, jobs);
     }
+    trace_end(st, ts);
     int e = fh_launch_status();
     if (e) return e;
   }

@@ -92,6 +92,8 @@ SIGNATURES = {
     "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "fhvae_trace_enable": (C.c_int, [C.c_int]),
+    "fhvae_trace_collect": (_i64, [_vp, _vp, _vp, _i64]),
     "fhvae_to_time_major": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
     "fhvae_cast_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
 }
@@ -154,6 +156,25 @@ class _OpTimer:
 
 
 OP_TIMER = _OpTimer()
+
+
+def cell_trace(enable: bool):
+    """Turn the in-library per-launch event trace of the LSTM step cells on/off (clears it)."""
+    _check(load_library().fhvae_trace_enable(int(enable)), "fhvae_trace_enable")
+
+
+def cell_trace_collect(cap: int = 65536):
+    """-> dict kind -> (launches, total_ms, total_flops); kinds: 0 forward cell, 1 backward cell."""
+    lib = load_library()
+    ms = (C.c_float * cap)()
+    kind = (C.c_int32 * cap)()
+    fl = (C.c_double * cap)()
+    n = int(lib.fhvae_trace_collect(ms, kind, fl, cap))
+    out = {}
+    for i in range(n):
+        c, t, f = out.get(kind[i], (0, 0.0, 0.0))
+        out[kind[i]] = (c + 1, t + ms[i], f + fl[i])
+    return out
 
 
 class _Timed:
