@@ -430,6 +430,10 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     if (B >= 16384) {  // large tiles only pay once they still give >= 2 workgroups per CU (see gemm.hip)
       dim3 grid((unsigned)fh_cdiv(H, 32), (unsigned)fh_cdiv(B, 128), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 128, 128, 2, 2, 16>), grid, dim3(kThreads), 0, st, jobs);
+    } else if (B >= 1024) {
+      // many workgroups per CU: 256-byte panels (32 KB LDS) so 2 workgroups per CU keep twice the bytes in flight
+      dim3 grid((unsigned)fh_cdiv(H, 16), (unsigned)fh_cdiv(B, 64), (unsigned)nj);
+      hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 64, 64, 4, 1, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else {
       dim3 grid((unsigned)fh_cdiv(H, 16), (unsigned)fh_cdiv(B, 64), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 64, 64, 4, 1, kCH>), grid, dim3(kThreads), 0, st, jobs);
@@ -502,6 +506,9 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     if (B >= 16384) {
       dim3 grid((unsigned)fh_cdiv(H, 64), (unsigned)fh_cdiv(B, 128), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 128, 64, 4, 1, 16>), grid, dim3(kThreads), 0, st, jobs);
+    } else if (B >= 1024) {
+      dim3 grid((unsigned)fh_cdiv(H, 32), (unsigned)fh_cdiv(B, 32), (unsigned)nj);
+      hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 32, 32, 2, 2, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else {
       dim3 grid((unsigned)fh_cdiv(H, 32), (unsigned)fh_cdiv(B, 32), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 32, 32, 2, 2, kCH>), grid, dim3(kThreads), 0, st, jobs);
