@@ -244,6 +244,30 @@ int fhvae_adam_step(float* p, const float* g, float* m, float* v, void* p_lp, in
 int fhvae_trace_enable(int on);
 int64_t fhvae_trace_collect(float* ms, int32_t* kind, double* flops, int64_t cap);
 
+/* ------------------------------------------------------------------------------------------
+ * SURVEY 8f "next" #1 -- segment sampler over an utterance pool resident in HBM.
+ * pool: (pool_frames, F) f32, all utterances of a split concatenated (288 GB of HBM hold ~900 M frames of
+ * 80-bin features); start[b]: absolute first frame of segment b in the pool (= utterance offset + seg.start,
+ * datasets.py:155-185).  Writes the (B,T,F) batch-major batch the reference's DataLoader would collate
+ * (datasets.py:214-223) and/or its time-major (T,B,F) form, with (x - mean) * inv_std applied per feature
+ * when mean/inv_std are given (apply_mvn, datasets.py:100-105).  Frames outside the pool read as 0 and set
+ * *oob_flag (int32 device word, may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+int fhvae_segment_gather(const float* pool, int64_t pool_frames, const int64_t* start, const float* mean,
+                         const float* inv_std, float* out_btf, float* out_tbf, int64_t B, int64_t T,
+                         int64_t F, int32_t* oob_flag, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SURVEY 8f "next" #2 -- closed-form mu2 estimate (utils.estimate_mu2_dict, utils.py:45-60):
+ *   mu2[y] = sum_{segments n with idx[n] == y} z2_mu[n] / (count[y] + ratio),  ratio = exp(pz2_logvar)/exp(pmu2_logvar)
+ * accumulate: zsum[idx[n],:] += z2_mu[n,:], count[idx[n]] += 1 (float atomics; call once per batch, buffers
+ * zeroed by the caller); finalize: mu2 = zsum / (count + ratio), 0 for sequences without segments.
+ * ------------------------------------------------------------------------------------------ */
+int fhvae_mu2_accumulate(const float* z2_mu, const int64_t* idx, float* zsum, float* count, int64_t N,
+                         int64_t S, int64_t D, void* stream);
+int fhvae_mu2_finalize(const float* zsum, const float* count, float* mu2, int64_t S, int64_t D,
+                       float ratio, void* stream);
+
 /* small utilities used by the host side */
 /* (B,T,F) batch-major f32 -> (T,B,F) time-major in operand dtype `dtype` (and optionally f32) */
 int fhvae_to_time_major(const float* x_btf, void* x_tbf, float* x_tbf_f32, int64_t B, int64_t T,

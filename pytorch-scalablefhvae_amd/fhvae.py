@@ -86,6 +86,20 @@ class FHVAE(FHVAEBase):
         """Table + gathered rows (simple_fhvae.py:39-54); the table persists instead of being redrawn."""
         return self.table_ops.lookup(mu_idx, num_seqs, mu2_table)
 
+    def encode(self, x: torch.Tensor):
+        """Inference-only latent extraction (eval_model.py:57-59 TODOs; used by utils.estimate_mu2_dict, utils.py:51-52):
+        returns (z1_mu, z2_mu) with z1 conditioned on the posterior MEAN of z2."""
+        x, _, _ = self._prep_inputs(x, torch.zeros(x.shape[0], dtype=torch.int64), 1)
+        T = x.shape[1]
+        dt = hb.BF16 if self.compute_dtype == "bf16" else hb.F32
+        x_tm = hb.to_time_major(x)
+        _, hn2 = self.z2_pre_encoder(x_tm, None, T, dt)
+        z2_mu, z2_logvar, _ = self.z2_gauss_layer(hn2, sample=False)
+        _, hn1 = self.z1_pre_encoder(x_tm, z2_mu, T, dt)
+        z1_mu, z1_logvar, _ = self.z1_gauss_layer(hn1, sample=False)
+        self.qz2_x = [z2_mu, z2_logvar]
+        return z1_mu, z2_mu
+
     def forward(self, x: torch.Tensor, mu_idx: torch.Tensor, num_seqs: int, num_segs, *, mu2_table=None, eps=None):
         x, mu_idx, num_segs = self._prep_inputs(x, mu_idx, num_segs)
         B, T, F_ = x.shape

@@ -56,6 +56,7 @@ class FHVAEBase(nn.Module):
         self.z2_dim = int(z2_dim)
         self.pz1 = [0.0, PZ1_LOGVAR]
         self.pmu2 = [0.0, PMU2_LOGVAR]
+        self.pz2 = [None, PZ2_LOGVAR]  # [mu2 of the last batch, logvar]; utils.py:58 reads pz2[1]
         self.reference_compat = bool(reference_compat)
         self._init_num_seqs = num_seqs
         self.table_ops = LocalTableOps(self)  # dist_shard.DistributedFHVAE swaps in the row-sharded ops

@@ -92,6 +92,9 @@ SIGNATURES = {
     "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "fhvae_segment_gather": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "fhvae_mu2_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_mu2_finalize": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "fhvae_trace_enable": (C.c_int, [C.c_int]),
     "fhvae_trace_collect": (_i64, [_vp, _vp, _vp, _i64]),
     "fhvae_to_time_major": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
@@ -634,3 +637,47 @@ def adam_step_(p, g, m, v, step_dev, lr, beta1, beta2, eps, grad_scale=1.0, p_lp
     with _Timed("fhvae_adam_step"):
         _check(lib.fhvae_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, lr, beta1, beta2, eps, grad_scale, _p(step_dev),
                                    _stream()), "fhvae_adam_step")
+
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8f "next" rows: resident-pool segment sampler and closed-form mu2 estimate
+# ---------------------------------------------------------------------------------------------
+def segment_gather(pool, start, T, mean=None, inv_std=None, time_major=False):
+    """Cut B segments of T frames out of the HBM-resident utterance pool (frames, F) at absolute frame offsets
+    `start` (B,) int64, with optional fused mean/variance normalisation.  Returns (B,T,F) (and (T,B,F) if asked)."""
+    lib = load_library()
+    _need_gpu(pool, start, mean, inv_std)
+    pool = _f32c(pool)
+    B, F_ = start.shape[0], pool.shape[1]
+    out = torch.empty(B, T, F_, device=pool.device, dtype=torch.float32)
+    out_tm = torch.empty(T, B, F_, device=pool.device, dtype=torch.float32) if time_major else None
+    with _Timed("fhvae_segment_gather"):
+        _check(lib.fhvae_segment_gather(_p(pool), pool.shape[0], _p(start), _p(mean), _p(inv_std), _p(out), _p(out_tm), B, T, F_,
+                                        None, _stream()), "fhvae_segment_gather")
+    return (out, out_tm) if time_major else out
+
+
+class Mu2Estimator:
+    """Running closed-form mu2 estimate over batches (utils.py:45-60) on the device."""
+
+    def __init__(self, num_seqs: int, dim: int, device):
+        self.S, self.D = int(num_seqs), int(dim)
+        self.zsum = torch.zeros(self.S, self.D, device=device, dtype=torch.float32)
+        self.count = torch.zeros(self.S, device=device, dtype=torch.float32)
+
+    def add(self, z2_mu, idx):
+        lib = load_library()
+        _need_gpu(z2_mu, idx)
+        z2_mu = _f32c(z2_mu.detach())
+        with _Timed("fhvae_mu2_accumulate"):
+            _check(lib.fhvae_mu2_accumulate(_p(z2_mu), _p(idx), _p(self.zsum), _p(self.count), z2_mu.shape[0], self.S, self.D,
+                                            _stream()), "fhvae_mu2_accumulate")
+
+    def result(self, ratio: float):
+        lib = load_library()
+        mu2 = torch.empty_like(self.zsum)
+        with _Timed("fhvae_mu2_finalize"):
+            _check(lib.fhvae_mu2_finalize(_p(self.zsum), _p(self.count), _p(mu2), self.S, self.D, float(ratio), _stream()),
+                   "fhvae_mu2_finalize")
+        return mu2, self.count

@@ -102,6 +102,15 @@ class SimpleFHVAE(FHVAEBase):
         """Table + gathered rows (simple_fhvae.py:39-54); the table persists instead of being redrawn."""
         return self.table_ops.lookup(mu_idx, num_seqs, mu2_table)
 
+    def encode(self, x: torch.Tensor):
+        """Inference-only latent extraction (eval_model.py:57-59 TODOs; used by utils.estimate_mu2_dict, utils.py:51-52):
+        returns (z1_mu, z2_mu) with z1 conditioned on the posterior MEAN of z2."""
+        x, _, _ = self._prep_inputs(x, torch.zeros(x.shape[0], dtype=torch.int64), 1)
+        z2_mu, z2_logvar, _ = self.z2_gauss_layer(self.z2_pre_encoder(x), sample=False)
+        z1_mu, z1_logvar, _ = self.z1_gauss_layer(self.z1_pre_encoder(x, z2_mu), sample=False)
+        self.qz2_x = [z2_mu, z2_logvar]
+        return z1_mu, z2_mu
+
     def forward(self, x: torch.Tensor, mu_idx: torch.Tensor, num_seqs: int, num_segs, *, mu2_table=None, eps=None):
         x, mu_idx, num_segs = self._prep_inputs(x, mu_idx, num_segs)
         B, T, F_ = x.shape

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     import hip_binding as hb
 
     names = _declared()
-    assert len(names) >= 23
+    assert len(names) >= 26
     for n in names:
         assert hasattr(lib, n), "libfhvae_hip.so lacks %s" % n
         assert n in hb.SIGNATURES, "hip_binding does not bind %s" % n
