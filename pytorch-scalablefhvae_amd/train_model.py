@@ -65,6 +65,19 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--train-segments", type=int, default=1000)
     p.add_argument("--dev-segments", type=int, default=250)
     p.add_argument("--seed", type=int, default=0)
+    # real features in the reference's on-disk format (feats.scp / len.scp of .npy files, prepare_numpy_data.py:115-119)
+    p.add_argument("--train-feat-scp", default=None)
+    p.add_argument("--train-len-scp", default=None)
+    p.add_argument("--dev-feat-scp", default=None)
+    p.add_argument("--dev-len-scp", default=None)
+    p.add_argument("--min-len", type=int, default=None)            # train_model.py:106-112 (defaults to seg_len, :267-268)
+    p.add_argument("--mvn-path", default=None)                     # :113-119
+    p.add_argument("--seg-shift", type=int, default=8)             # :124-126
+    p.add_argument("--rand-seg", action="store_true")
+    p.add_argument("--exp-dir", default=None, help="write the reference-layout checkpoint there after every epoch")
+    p.add_argument("--hierarchical", dest="sample_hierarchical", action="store_true",   # train_model.py:203-214
+                   help="re-estimate the mu2 table in closed form from the encoder before training (utils.py:45-60)")
+    p.add_argument("--compute-dtype", default="f32", choices=["f32", "bf16"])
     p.add_argument("--paper-objective", action="store_true",
                    help="train the intended objective (decoder attached, log_qy=-CE) instead of the reference's literal one")
     return p
@@ -88,30 +101,84 @@ def main(argv=None) -> int:
     from simple_fhvae import SimpleFHVAE
 
     torch.manual_seed(args.seed)
-    T, F, S = args.seg_len, args.mels, args.num_seqs
+    T, F = args.seg_len, args.mels
+    real = args.train_feat_scp is not None
+    if real:
+        from datasets import NumpyDataset, ResidentSegmentPool
+
+        min_len = args.min_len if args.min_len is not None else T  # train_model.py:267-268
+        tr_ds = NumpyDataset(args.train_feat_scp, args.train_len_scp, min_len, args.mvn_path, T, args.seg_shift, args.rand_seg)
+        dv_ds = NumpyDataset(args.dev_feat_scp or args.train_feat_scp, args.dev_len_scp or args.train_len_scp, min_len,
+                             args.mvn_path, T, args.seg_shift, False)
+        tr_pool, dv_pool = ResidentSegmentPool(tr_ds, device), ResidentSegmentPool(dv_ds, device)
+        F = tr_pool.pool.shape[1]
+        S = len(tr_ds)  # len(train_loader.dataset), train_model.py:448
+    else:
+        S = args.num_seqs
     input_size = T * F  # np.prod(example_data.shape), train_model.py:396-398
     kw = dict(num_seqs=S, reference_compat=not args.paper_objective)
     if args.model_type == "fhvae":
-        model = FHVAE(input_size, args.z1_hus, args.z2_hus, args.z1_dim, args.z2_dim, args.x_hus, seg_len=T, **kw)
+        model = FHVAE(input_size, args.z1_hus, args.z2_hus, args.z1_dim, args.z2_dim, args.x_hus, seg_len=T,
+                      compute_dtype=args.compute_dtype, **kw)
     else:
         model = SimpleFHVAE(input_size, args.z1_hus, args.z2_hus, args.z1_dim, args.z2_dim, args.x_hus, **kw)
     model.to(device)
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate, betas=(args.beta_one, args.beta_two))
+    from hip_optim import FusedAdam
 
-    xtr, itr, ntr = synthetic_split(args.train_segments, T, F, S, args.seed + 1)
-    xdv, idv, ndv = synthetic_split(args.dev_segments, T, F, S, args.seed + 2)
-    xtr, xdv = xtr.to(device), xdv.to(device)
+    optimizer = FusedAdam(model.parameters(), lr=args.learning_rate, betas=(args.beta_one, args.beta_two))
+
+    if real:
+        def train_batches():
+            return tr_pool.epoch(args.training_batch_size, shuffle=True)
+
+        def dev_batches():
+            return dv_pool.epoch(args.dev_batch_size, shuffle=False)
+
+        n_train = len(tr_pool)
+    else:
+        xtr, itr, ntr = synthetic_split(args.train_segments, T, F, S, args.seed + 1)
+        xdv, idv, ndv = synthetic_split(args.dev_segments, T, F, S, args.seed + 2)
+        xtr, xdv = xtr.to(device), xdv.to(device)
+
+        def train_batches():
+            perm = torch.randperm(xtr.shape[0])
+            for s0 in range(0, xtr.shape[0], args.training_batch_size):
+                sel = perm[s0:s0 + args.training_batch_size]
+                yield itr[sel], xtr[sel], ntr[sel]
+
+        def dev_batches():
+            for s0 in range(0, xdv.shape[0], args.dev_batch_size):
+                yield idv[s0:s0 + args.dev_batch_size], xdv[s0:s0 + args.dev_batch_size], ndv[s0:s0 + args.dev_batch_size]
+
+        n_train = xtr.shape[0]
+
+    if args.sample_hierarchical:
+        # closed-form mu2 from the current encoder (train_model.py:424-436); unlike the reference the result is USED:
+        # it initialises the persistent table
+        from utils import estimate_mu2_dict
+
+        mu2_dict = estimate_mu2_dict(model, train_batches(), S)
+        with torch.no_grad():
+            for y, v in mu2_dict.items():
+                model.mu2_table[y] = v
+        print(f"hierarchical: mu2 re-estimated for {len(mu2_dict)} of {S} sequences")
+    if args.exp_dir:
+        import os
+
+        os.makedirs(args.exp_dir, exist_ok=True)
+        from utils import save_args, save_checkpoint
+
+        save_args(args.exp_dir, args)  # train_model.py:422
+
     best_epoch, best_val_lb = 0, -np.inf
     for epoch in range(args.epochs):
         model.train()
         t0 = time.time()
         train_loss = torch.zeros((), device=device)
-        perm = torch.randperm(xtr.shape[0])
         nb = 0
-        for s in range(0, xtr.shape[0], args.training_batch_size):
-            sel = perm[s:s + args.training_batch_size]
+        for idxs, features, nsegs in train_batches():
             optimizer.zero_grad()
-            lower_bound, discrim_loss, log_px_z, neg_kld_z1, neg_kld_z2, log_pmu2 = model(xtr[sel], itr[sel], S, ntr[sel])
+            lower_bound, discrim_loss, log_px_z, neg_kld_z1, neg_kld_z2, log_pmu2 = model(features, idxs, S, nsegs)
             loss = loss_function(lower_bound, discrim_loss, args.alpha_dis)
             loss.backward()
             optimizer.step()
@@ -121,18 +188,20 @@ def main(argv=None) -> int:
                 print("Training diverged")
                 return 2  # sys.exit(2), train_model.py:464-466
         dt = time.time() - t0
-        print(f"====> Train set average loss: {train_loss.item() / nb:.4f}  ({xtr.shape[0] / dt:.0f} segments/s)")
+        print(f"====> Train set average loss: {train_loss.item() / nb:.4f}  ({n_train / dt:.0f} segments/s)")
         model.eval()
         lbs = []
         with torch.no_grad():
-            for s in range(0, xdv.shape[0], args.dev_batch_size):
-                out = model(xdv[s:s + args.dev_batch_size], idv[s:s + args.dev_batch_size], S, ndv[s:s + args.dev_batch_size])
-                lbs.append(out[0])
+            for idxs, features, nsegs in dev_batches():
+                lbs.append(model(features, idxs, S, nsegs)[0])
         val_lower_bound = torch.cat(lbs)
         print(f"====> Validation set lower bound: {val_lower_bound.mean().item():.4f} "
               f"({val_lower_bound.mean().item() / T:.4f} nats/frame)")
         if check_best(val_lower_bound, best_val_lb):
             best_epoch, best_val_lb = epoch, val_lower_bound.mean().item()
+        if args.exp_dir:
+            save_checkpoint(model, optimizer, None, {"val_lower_bound": val_lower_bound.mean().item()}, "run", epoch, best_epoch,
+                            val_lower_bound.mean().item(), best_val_lb, args.exp_dir, input_size=input_size)
         if check_terminate(epoch, best_epoch, args.patience, args.epochs):
             print("Training terminated!")
             break

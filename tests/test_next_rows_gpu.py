@@ -79,3 +79,24 @@ def test_encode_matches_oracle(hb):
         z1_ref = ref.z1_gauss_layer(ref.z1_pre_encoder(torch.cat([xf, z2_ref], -1)))[0]
     close(z2, z2_ref, what="z2_mu")
     close(z1, z1_ref, what="z1_mu")
+
+
+def test_train_model_main_real_scp_and_synthetic(hb, corpus, tmp_path, capsys):
+    """The train_model-shaped loop end to end on the GPU: scp/npy corpus through the resident pool, hierarchical mu2
+    initialisation, reference-layout checkpoints; then the synthetic default with SimpleFHVAE."""
+    import train_model as TM
+    import utils as U
+
+    root, _ = corpus
+    exp = tmp_path / "exp"
+    rc = TM.main(["--train-feat-scp", str(root / "feats.scp"), "--train-len-scp", str(root / "len.scp"), "--mvn-path",
+                  str(root / "mvn2.json"), "--z1-hus", "16", "16", "--z2-hus", "16", "16", "--x-hus", "16", "16", "--z1-dim", "8",
+                  "--z2-dim", "8", "--epochs", "2", "--training-batch-size", "8", "--exp-dir", str(exp), "--hierarchical",
+                  "--paper-objective"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "Training complete!" in out and "hierarchical: mu2 re-estimated for 3 of 3" in out
+    m = U.load_checkpoint_file(exp / "fhvae_run_e1.tar", finetune=True)[0]
+    assert m.mu2_table.shape == (3, 8) and m.n_feat == 8
+    rc = TM.main(["--model-type", "simple_fhvae", "--epochs", "1", "--train-segments", "64", "--dev-segments", "32",
+                  "--training-batch-size", "32", "--num-seqs", "10"])
+    assert rc == 0
