@@ -132,6 +132,9 @@ typedef struct fhvae_lstm_bwd_desc {
   float* db_ih[FHVAE_MAX_LAYERS];
   float* db_hh[FHVAE_MAX_LAYERS];
   float* d_xc;    /* (B,Ic) f32, OVERWRITTEN (may be NULL) */
+  int32_t phase;  /* 0: everything; 1: the recurrence (dgates, dgsum, d_xc) only; 2: the weight/bias gradient
+                     contractions only (reads what phase 1 left in dgates/dgsum) -- lets the host put phase 2 on a
+                     second stream, under the next net's latency-bound recurrence */
 } fhvae_lstm_bwd_desc;
 
 int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* d, void* stream);

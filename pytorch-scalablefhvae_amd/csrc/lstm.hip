@@ -570,19 +570,22 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
     e = launch_colsum(dgl, d->dtype, G, bd->db_ih[l], bd->db_hh[l], T_ * B, G, st);
     if (e) return e;
   }
-  if (bd->d_xc && Ic > 0) {
-    // d_xc[B,Ic] = dgsum[B,4H] . W_ih0[:, I:]   (f32 master weight as KM operand: B(n, k) = W[k*K0 + I + n])
-    GemmParams p = {};
-    p.seg[0] = Seg{bd->dgsum, G, 1, d->w_ih[0] + I, K0, 0, (int)G, 0};
-    p.M = (int)B;
-    p.N = (int)Ic;
-    p.C = bd->d_xc;
-    p.ldc = Ic;
-    p.splitk = 1;
-    int e = launch_gemm(p, FHVAE_F32, st);
-    if (e) return e;
-  }
   return FHVAE_OK;
+}
+
+// d_xc[B,Ic] = dgsum[B,4H] . W_ih0[:, I:]   (f32 master weight as KM operand: B(n, k) = W[k*K0 + I + n])
+static int lstm_dxc(const fhvae_lstm_bwd_desc* bd, hipStream_t st) {
+  const fhvae_lstm_desc* d = &bd->f;
+  if (!bd->d_xc || d->Ic <= 0) return FHVAE_OK;
+  const int64_t G = 4 * d->H, K0 = d->I + d->Ic;
+  GemmParams p = {};
+  p.seg[0] = Seg{bd->dgsum, G, 1, d->w_ih[0] + d->I, K0, 0, (int)G, 0};
+  p.M = (int)d->B;
+  p.N = (int)d->Ic;
+  p.C = bd->d_xc;
+  p.ldc = d->Ic;
+  p.splitk = 1;
+  return launch_gemm(p, FHVAE_F32, st);
 }
 
 extern "C" int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* bd, void* stream) {
@@ -593,16 +596,26 @@ extern "C" int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* bd, void* stream) {
   FH_CHECK_PTR(bd->dgates);
   FH_CHECK_PTR(bd->dc);
   if (d->Ic > 0) FH_CHECK_PTR(bd->dgsum);
-  if (!bd->d_hs_top && !bd->d_hn) return FHVAE_ERR_NULL;
+  if (bd->phase < 0 || bd->phase > 2) return FHVAE_ERR_SHAPE;
+  const bool rec = bd->phase != 2, par = bd->phase != 1;
+  if (rec && !bd->d_hs_top && !bd->d_hn) return FHVAE_ERR_NULL;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == FHVAE_F32) {
     Ops<float> op = ops_f32(d);
-    e = lstm_bwd_impl<float>(bd, op, st);
-    if (e) return e;
-    return lstm_param_grads<float>(bd, op, st);
+    if (rec) {
+      e = lstm_bwd_impl<float>(bd, op, st);
+      if (e) return e;
+      e = lstm_dxc(bd, st);
+      if (e) return e;
+    }
+    return par ? lstm_param_grads<float>(bd, op, st) : FHVAE_OK;
   }
   Ops<u16> op = ops_bf16(d);  // filled by the forward
-  e = lstm_bwd_impl<u16>(bd, op, st);
-  if (e) return e;
-  return lstm_param_grads<u16>(bd, op, st);
+  if (rec) {
+    e = lstm_bwd_impl<u16>(bd, op, st);
+    if (e) return e;
+    e = lstm_dxc(bd, st);
+    if (e) return e;
+  }
+  return par ? lstm_param_grads<u16>(bd, op, st) : FHVAE_OK;
 }

@@ -44,7 +44,7 @@ class LstmBwdDesc(C.Structure):
         ("dgates", _vp), ("dgsum", _vp), ("dc", _vp),
         ("dw_ih", _vp * MAX_LAYERS), ("dw_hh", _vp * MAX_LAYERS),
         ("db_ih", _vp * MAX_LAYERS), ("db_hh", _vp * MAX_LAYERS),
-        ("d_xc", _vp),
+        ("d_xc", _vp), ("phase", _i32),
     ]
 
 
@@ -123,6 +123,35 @@ def load_library(path: str = LIB_PATH):
         raise RuntimeError("libfhvae_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+# ---------------------------------------------------------------------------------------------
+# second stream: the weight-gradient contractions of a net (wide GEMMs, many workgroups) run there, under the
+# next net's recurrence (<= 128 workgroups per launch, latency-bound).  Used only when every parameter has a
+# gradient sink (hip_optim.FusedAdam): nothing downstream reads those gradients before the optimizer, which joins.
+# ---------------------------------------------------------------------------------------------
+# MEASURED (MI355X, c2, B=256, bf16): enabling it made the step SLOWER (2.61 -> 2.98 ms under graph replay): the
+# concurrent GEMM workgroups take L2/LDS bandwidth from the latency-bound cells on the critical path.  Off by default.
+_SIDE = {"stream": None, "pending": False, "keep": [], "enabled": False}
+
+
+def side_stream():
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream()
+    return _SIDE["stream"]
+
+
+def join_side_stream():
+    """Make the current stream wait for the side stream's pending work (call before reading the gradient arena)."""
+    if _SIDE["pending"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["pending"] = False
+        _SIDE["keep"].clear()  # safe to release: the current stream is now ordered after their last use
+
+
+def set_side_stream_enabled(on: bool):
+    join_side_stream()
+    _SIDE["enabled"] = bool(on)
 
 
 class _OpTimer:
@@ -440,8 +469,23 @@ class _LstmSeq(torch.autograd.Function):
         for l in range(L):
             bd.dw_ih[l], bd.dw_hh[l], bd.db_ih[l], bd.db_hh[l] = (_p(grads[4 * l + k]) for k in range(4))
         bd.d_xc = _p(d_xc)
-        with _Timed("fhvae_lstm_seq_bwd"):
-            _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
+        if _SIDE["enabled"] and all(sk is not None for sk in ctx.sinks):
+            # recurrence on this stream; the weight-gradient contractions on the side stream, joined by the optimizer
+            bd.phase = 1
+            with _Timed("fhvae_lstm_seq_bwd"):
+                _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
+            main, side = torch.cuda.current_stream(), side_stream()
+            side.wait_stream(main)
+            bd.phase = 2
+            with torch.cuda.stream(side):
+                with _Timed("fhvae_lstm_seq_bwd(param grads, side stream)"):
+                    _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
+            _SIDE["pending"] = True
+            _SIDE["keep"].append((x_tm, xc, hs, cs, gates, lp, dgates, dgsum, dc, d_hs_top, d_hn, params))
+        else:
+            bd.phase = 0
+            with _Timed("fhvae_lstm_seq_bwd"):
+                _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
         return (None, d_xc, None, None, *[None if sk is not None else g for g, sk in zip(grads, ctx.sinks)])
 
 

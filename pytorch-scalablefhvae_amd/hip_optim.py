@@ -51,16 +51,19 @@ class FusedAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = False):
         # keep the arena views attached (set_to_none would detach them); one memset for everything
+        hb.join_side_stream()
         self.g_arena.flat.zero_()
         for p, gv in zip(self._params, self.g_arena.views):
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
                 p.grad = gv
 
     def flat_grad(self) -> torch.Tensor:
+        hb.join_side_stream()  # weight-gradient GEMMs may still be running on the side stream
         return self.g_arena.flat
 
     @torch.no_grad()
     def step(self, closure=None):
+        hb.join_side_stream()
         for p, gv in zip(self._params, self.g_arena.views):
             if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():
                 gv.copy_(p.grad)  # a gradient produced outside the arena (first backward after set_to_none)
