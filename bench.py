@@ -189,7 +189,7 @@ def main():
     ok = bool(torch.isfinite(loss).item())
 
     roof = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:  # every rank runs the instrumented steps (they contain collectives); rank 0 reports
         # Instrumented EAGER repeat of the same steps: (1) HIP events (torch's current stream == the launch stream)
         # around every C-ABI call, (2) the library's own per-launch event pairs around every LSTM step-cell
         # launch, each tagged with its algorithmic FLOPs (fhvae_trace_*).  The dominant kernel is the cell kind
@@ -219,7 +219,7 @@ def main():
                 traffic = json.load(open(tf)).get("%s_%s_B%d" % (names[dom], args.dtype, B))
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": "%s<%s>" % (names[dom], args.dtype), "achieved": ach, "peak": peak,
+        roof = None if rank != 0 else {"bound": "mfma", "kernel": "%s<%s>" % (names[dom], args.dtype), "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "launches_per_step": n / args.steps, "avg_launch_us": t_ms / n * 1e3,
                 "flops_per_launch": fl / n,

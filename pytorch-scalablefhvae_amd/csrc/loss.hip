@@ -264,20 +264,20 @@ __global__ __launch_bounds__(256) void disc_combine_kernel(const float* __restri
   const float gm = wave_max(m);
   sum = m == -INFINITY ? 0.f : sum * __expf(m - gm);
   sum = wave_sum(sum);
-  // target logit: lanes over d
+  // target logit with EXACTLY the arithmetic of disc_fwd_kernel (same sqdist order), so that a target that is the
+  // row maximum gives (max - target) == 0 bit for bit
   const int64_t s = idx[b] - row0;
-  float a = 0.f;
-  if (s >= 0 && s < S) {
-    for (int d = lane; d < D; d += 64) {
-      const float df = q[(int64_t)b * D + d] - table[s * D + d];
-      a = fmaf(df, df, a);
-    }
-  }
-  a = wave_sum(a);
   if (lane == 0) {
+    float t = 0.f;
+    if (s >= 0 && s < S) {
+      float qr[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) qr[d] = q[(int64_t)b * D + d];
+      t = -c * sqdist<D>(qr, table + s * D);
+    }
     row_max[b] = gm;
     row_sum[b] = sum;
-    tgt[b] = (s >= 0 && s < S) ? -c * a : 0.f;
+    tgt[b] = t;
   }
 }
 

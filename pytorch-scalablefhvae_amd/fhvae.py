@@ -101,6 +101,7 @@ class FHVAE(FHVAEBase):
         return z1_mu, z2_mu
 
     def forward(self, x: torch.Tensor, mu_idx: torch.Tensor, num_seqs: int, num_segs, *, mu2_table=None, eps=None):
+        self._check_idx(mu_idx, num_seqs)
         x, mu_idx, num_segs = self._prep_inputs(x, mu_idx, num_segs)
         B, T, F_ = x.shape
         if F_ != self.n_feat:

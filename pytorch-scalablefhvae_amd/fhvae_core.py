@@ -80,6 +80,17 @@ class FHVAEBase(nn.Module):
         return self.mu2_table
 
     @staticmethod
+    def _check_idx(mu_idx, num_seqs):
+        """The reference's torch.gather raises on an out-of-range sequence index (simple_fhvae.py:53).  Indices that
+        arrive on the host (the reference loop builds them there, train_model.py:445) are range-checked for free;
+        device-resident indices are not (that would cost a device sync per step): out-of-range rows then read as 0."""
+        t = torch.as_tensor(mu_idx)
+        if not t.is_cuda and t.numel() > 0:
+            lo, hi = int(t.min()), int(t.max())
+            if lo < 0 or hi >= int(num_seqs):
+                raise IndexError("mu_idx out of range: [%d, %d] for a mu2 table of %d rows" % (lo, hi, num_seqs))
+
+    @staticmethod
     def _prep_inputs(x, mu_idx, num_segs):
         if not x.is_cuda:
             raise RuntimeError("FHVAE (HIP path) needs the model and inputs on a MI355X device; no CPU fallback")

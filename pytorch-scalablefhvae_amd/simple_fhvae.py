@@ -112,6 +112,7 @@ class SimpleFHVAE(FHVAEBase):
         return z1_mu, z2_mu
 
     def forward(self, x: torch.Tensor, mu_idx: torch.Tensor, num_seqs: int, num_segs, *, mu2_table=None, eps=None):
+        self._check_idx(mu_idx, num_seqs)
         x, mu_idx, num_segs = self._prep_inputs(x, mu_idx, num_segs)
         B, T, F_ = x.shape
         mu2_table, mu2 = self.mu2_lookup(mu_idx, self.z2_dim, num_seqs, mu2_table=mu2_table)

@@ -224,3 +224,25 @@ def test_fused_adam_grad_sinks_match_torch_adam(hb):
     b = run(lambda ps: FusedAdam(ps, lr=1e-3, betas=(0.95, 0.999)))
     for n in a:
         close(b[n], a[n], rtol=2e-4, what=n)
+
+
+def test_edge_cases_single_segment_single_row_and_bad_index(hb):
+    """B=1, S=1 (a one-row table: CE must be exactly 0), T=1, and the reference's IndexError for an out-of-range
+    sequence index arriving on the host."""
+    from fhvae import FHVAE
+    from simple_fhvae import SimpleFHVAE
+
+    torch.manual_seed(0)
+    m = SimpleFHVAE(4 * 8, [16, 16], [16, 16], 16, 16, [16, 16], num_seqs=1).cuda()
+    out = m(torch.randn(1, 4, 8).cuda(), torch.tensor([0]), 1, 5)
+    assert out[0].shape == (1,) and abs(out[1].item()) < 1e-6 and torch.isfinite(out[0]).all()
+    f = FHVAE(1 * 8, [8], [8], 4, 4, [8], seg_len=1, num_seqs=3).cuda()  # one frame per segment, one layer
+    ref = R.FHVAERef(8, [8], [8], 4, 4, [8], seg_len=1)
+    ref.load_state_dict({k: v.cpu() for k, v in f.state_dict().items() if k != "mu2_table"})
+    x, idx, e2, e1 = torch.randn(2, 1, 8), torch.tensor([2, 0]), torch.randn(2, 4), torch.randn(2, 4)
+    got = f(x.cuda(), idx, 3, 7, eps=(e2, e1))
+    want = ref(x, idx, 3, 7, mu2_table=f.mu2_table.detach().cpu(), eps_z2=e2, eps_z1=e1)
+    for k in range(6):
+        close(got[k], want[k], what="out%d" % k)
+    with pytest.raises(IndexError):
+        f(x.cuda(), torch.tensor([3, 0]), 3, 7)
