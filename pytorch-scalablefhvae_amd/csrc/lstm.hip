@@ -34,7 +34,7 @@ struct FwdJob {
   float* c_out;         // [B,H]
   T* h_out;             // [B,H] operand dtype
   float* h_out_f32;     // optional f32 copy of h (top layer in bf16 mode: feeds the f32 Gaussian head)
-  float* gates_out;     // [B,4H] activated i,f,g,o
+  T* gates_out;         // [B,4H] activated i,f,g,o (operand dtype: bf16 halves the cell's dominant HBM write)
   float* hn_out;        // optional slot in the (B, L*H) final-state buffer (t == T-1)
   int64_t hn_ld;
 };
@@ -63,6 +63,17 @@ __device__ __forceinline__ void store_h<float>(float* p, float v) {
 template <>
 __device__ __forceinline__ void store_h<u16>(u16* p, float v) {
   *p = f2bf(v);
+}
+
+template <typename T>
+__device__ __forceinline__ float load_h(const T* p);
+template <>
+__device__ __forceinline__ float load_h<float>(const float* p) {
+  return *p;
+}
+template <>
+__device__ __forceinline__ float load_h<u16>(const u16* p) {
+  return bf2f(*p);
 }
 
 // Tile shapes: <64,64,4,1> (more workgroups, epilogue operands prefetched) and <128,128,2,2> (very large
@@ -133,11 +144,11 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
       J.c_out[(int64_t)row * H + unit] = c;
       store_h<T>(J.h_out + (int64_t)row * H + unit, h);
       if (J.h_out_f32) J.h_out_f32[(int64_t)row * H + unit] = h;
-      float* go = J.gates_out + (int64_t)row * 4 * H + unit;
-      go[0] = ig;
-      go[H] = fg;
-      go[2 * H] = gg;
-      go[3 * H] = og;
+      T* go = J.gates_out + (int64_t)row * 4 * H + unit;
+      store_h<T>(go, ig);
+      store_h<T>(go + H, fg);
+      store_h<T>(go + 2 * H, gg);
+      store_h<T>(go + 3 * H, og);
       if (J.hn_out) J.hn_out[(int64_t)row * J.hn_ld + unit] = h;
     }
 }
@@ -153,7 +164,7 @@ struct BwdJob {
   int64_t ext_ld;
   const float* ext2;  // [B,H] slot of d_hn (t == T-1) or NULL
   int64_t ext2_ld;
-  const float* gates;   // [B,4H] saved activations
+  const T* gates;       // [B,4H] saved activations (operand dtype)
   const float* c_prev;  // [B,H] or NULL
   const float* c_cur;   // [B,H]
   float* dc;            // [B,H] running dL/dc (already multiplied by f of the later step)
@@ -199,8 +210,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
         float dh = acc[tm][tn][r];
         if (J.ext) dh += J.ext[(int64_t)row * J.ext_ld + unit];
         if (J.ext2) dh += J.ext2[(int64_t)row * J.ext2_ld + unit];
-        const float* gp = J.gates + (int64_t)row * 4 * H + unit;
-        const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+        const T* gp = J.gates + (int64_t)row * 4 * H + unit;
+        const float ig = load_h<T>(gp), fg = load_h<T>(gp + H), gg = load_h<T>(gp + 2 * H), og = load_h<T>(gp + 3 * H);
         const float cp = J.c_prev ? J.c_prev[o] : 0.f;
         const float tc = tanhf_(J.c_cur[o]);
         float dc = dh * og * (1.f - tc * tc);
@@ -418,7 +429,7 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
       J.c_out = d->cs + lt * B * H;
       J.h_out = hs + lt * B * H;
       if (l == L - 1 && d->hs_top_f32) J.h_out_f32 = d->hs_top_f32 + t * B * H;
-      J.gates_out = d->gates + lt * B * 4 * H;
+      J.gates_out = (T*)d->gates + lt * B * 4 * H;
       if (d->hn && t == T_ - 1) {
         J.hn_out = d->hn + (int64_t)l * H;
         J.hn_ld = (int64_t)L * H;
@@ -492,7 +503,7 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
         J.ext2 = bd->d_hn + (int64_t)l * H;
         J.ext2_ld = (int64_t)L * H;
       }
-      J.gates = d->gates + lt * B * 4 * H;
+      J.gates = (const T*)d->gates + lt * B * 4 * H;
       J.c_prev = t > 0 ? d->cs + (lt - 1) * B * H : nullptr;
       J.c_cur = d->cs + lt * B * H;
       J.dc = bd->dc + (int64_t)l * B * H;

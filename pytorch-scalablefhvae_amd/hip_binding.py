@@ -425,7 +425,7 @@ class _LstmSeq(torch.autograd.Function):
         bf = dtype == BF16
         hs = torch.empty(L, T, B, H, device=dev, dtype=torch.bfloat16 if bf else torch.float32)
         cs = torch.empty(L, T, B, H, **f32)
-        gates = torch.empty(L, T, B, 4 * H, **f32)
+        gates = torch.empty(L, T, B, 4 * H, device=dev, dtype=hs.dtype)
         hn = torch.empty(B, L * H, **f32)
         pre = torch.empty((T if I > 0 else 1), B, 4 * H, **f32)
         hs_top = torch.empty(T, B, H, **f32) if bf else None
