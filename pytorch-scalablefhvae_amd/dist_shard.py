@@ -175,21 +175,72 @@ class DistributedFHVAE:
         self.shard = nn.Parameter(full[self.sh.row0:self.sh.row1].clone())
         model.mu2_table = None  # the full table is dropped: only the shard stays resident
         model.table_ops = ShardedTableOps(self.shard, self.sh)
-        nets = [p for p in model.parameters() if p.requires_grad]
+        # Gradient buckets in the order their backward COMPLETES (decoder first, z2 encoder last): each bucket is
+        # contiguous in the flat arena, and its all-reduce is started (async, RCCL's own stream) as soon as the net's
+        # backward recurrence has been enqueued, i.e. it overlaps the next net's latency-bound backward cells (C1).
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+
+        def group_of(name):
+            if name.startswith(("pre_decoder", "dec_gauss_layer")):
+                return 0
+            return 1 if name.startswith("z1_") else 2
+
+        nets = [p for g in (0, 1, 2) for n, p in named if group_of(n) == g]
+        counts = [sum(1 for n, _ in named if group_of(n) == g) for g in (0, 1, 2)]
         for p in nets:  # replicas start identical
             dist.broadcast(p.data, 0, group=group)
         self.opt_nets = FusedAdam(nets, lr=lr, betas=betas, eps=eps, grad_scale=1.0 / self.sh.world)
         self.opt_table = FusedAdam([self.shard], lr=lr, betas=betas, eps=eps, grad_scale=1.0)
+        offs = self.opt_nets.g_arena.offsets + [self.opt_nets.g_arena.numel]
+        bounds, k = [], 0
+        for c in counts:
+            bounds.append((offs[k], offs[k + c]))
+            k += c
+        self._buckets = bounds                      # [(begin, end)) of each group in the flat gradient arena
+        self._bucket_of_ptr = {}
+        k = 0
+        for g, c in enumerate(counts):
+            for v in self.opt_nets.g_arena.views[k:k + c]:
+                self._bucket_of_ptr[v.data_ptr()] = g
+            k += c
+        self._pending = {}
+        self.overlap = True
+
+    def _on_lstm_bwd_done(self, sinks):
+        """Fired by hip_binding at the end of an LSTM net's backward: that net's Gaussian head ran earlier in the
+        backward pass, so the whole bucket is final -> start its all-reduce now."""
+        if not self.overlap or not sinks or sinks[0] is None:
+            return
+        g = self._bucket_of_ptr.get(sinks[0].data_ptr())
+        if g is None or g in self._pending:
+            return
+        b, e = self._buckets[g]
+        self._pending[g] = dist.all_reduce(self.opt_nets.g_arena.flat[b:e], group=self.sh.group, async_op=True)
+
+    def _reduce_gradients(self):
+        flat = self.opt_nets.flat_grad()
+        for g, (b, e) in enumerate(self._buckets):
+            if g in self._pending:
+                self._pending[g].wait()
+            elif e > b:
+                dist.all_reduce(flat[b:e], group=self.sh.group)
+        self._pending.clear()
 
     def train_step(self, x, idx, nsegs, alpha=10.0):
         from train_model import loss_function
+
+        import hip_binding as hb
 
         self.opt_nets.zero_grad()
         self.opt_table.zero_grad()
         out = self.model(x, idx, self.sh.S, nsegs)
         loss = loss_function(out[0], out[1], alpha)
-        loss.backward()
-        dist.all_reduce(self.opt_nets.flat_grad(), group=self.sh.group)  # C1: one collective over the arena
+        hb.LSTM_BWD_DONE_HOOK["fn"] = self._on_lstm_bwd_done
+        try:
+            loss.backward()
+        finally:
+            hb.LSTM_BWD_DONE_HOOK["fn"] = None
+        self._reduce_gradients()  # C1: three bucket all-reduces, two of them already in flight under the backward
         self.opt_nets.step()
         self.opt_table.step()
         return loss.detach(), out[0].detach()

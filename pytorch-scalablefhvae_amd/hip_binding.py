@@ -135,6 +135,11 @@ def load_library(path: str = LIB_PATH):
 _SIDE = {"stream": None, "pending": False, "keep": [], "enabled": False}
 
 
+#: optional callback(params_tuple) fired at the end of every _LstmSeq.backward: the data-parallel wrapper uses it to
+#: start the all-reduce of a net's gradient bucket while the next net's backward recurrence still runs
+LSTM_BWD_DONE_HOOK = {"fn": None}
+
+
 def side_stream():
     if _SIDE["stream"] is None:
         _SIDE["stream"] = torch.cuda.Stream()
@@ -486,6 +491,8 @@ class _LstmSeq(torch.autograd.Function):
             bd.phase = 0
             with _Timed("fhvae_lstm_seq_bwd"):
                 _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
+        if LSTM_BWD_DONE_HOOK["fn"] is not None:
+            LSTM_BWD_DONE_HOOK["fn"](ctx.sinks)
         return (None, d_xc, None, None, *[None if sk is not None else g for g, sk in zip(grads, ctx.sinks)])
 
 
