@@ -1,0 +1,358 @@
+// disc_mfma.hip -- K5 on the matrix cores (large tables; simple_fhvae.py:119-122).
+//
+//   logit[b,s] = -c |q_b - t_s|^2 = 2c (q_b . t_s) - c |q_b|^2 - c |t_s|^2
+//
+// The cross term q.t is a (B x S x D) contraction: it runs on exact-f32 MFMA (v_mfma_f32_16x16x4_f32: every product
+// and every accumulation step is an f32 fma, so the expanded form costs only the cancellation of the norms, ~1e-5
+// absolute on logits of 10..1000), and the exp / online log-sum-exp runs on the VALU under it (separate pipes).
+// The VALU kernels in loss.hip spend 2*D lane-instructions per (query,row) pair on the distance alone.
+//
+// One kernel template, three uses.  A workgroup keeps 256 STATIONARY vectors X (64 per wave, as MFMA B-operand
+// fragments in registers) and streams the other set Y through LDS in tiles of 64:
+//   MODE 0  forward   X = queries,    Y = table rows : per-query online (max, sumexp) partials per row chunk
+//   MODE 1  dq        X = queries,    Y = table rows : G_x = sum_y w[y,x] Y_y  on MFMA again -> dq = 2c (G - q W)
+//   MODE 1  dtable    X = table rows, Y = queries    : same formula gives dt = 2c (G - t W)
+// with w = g (softmax - onehot) recomputed from the per-query (max, sumexp) of the forward.  The logit tile comes out
+// of the MFMA with the stationary index on the lanes (col = lane&15) and the streamed index in the 4 accumulator
+// registers (row = 4*(lane>>4)+r): exactly the B-operand layout of the second product, so w never leaves registers.
+#include "common.h"
+
+namespace fh {
+
+struct DiscMfmaArgs {
+  const float* X;  // stationary [NX, D]
+  const float* Y;  // streamed   [NY, D]
+  int NX, NY;
+  float c;
+  int x_is_query;
+  const int64_t* idx;  // per QUERY target row (global); query b hits local row idx[b] - row0
+  int64_t row0;
+  const float* rmax;   // per query (MODE 1)
+  const float* rsum;
+  const float* gsc;    // device scalar
+  float gmul;
+  float2* part;        // MODE 0: [nchunks][NX]
+  float* G;            // MODE 1: [NX, D] accumulated with atomics
+  int chunk;           // streamed vectors per workgroup (multiple of 64)
+};
+
+template <int D>
+__device__ __forceinline__ int yoff(int row, int ch) {  // byte offset of 16-byte chunk ch of LDS row `row`
+  constexpr int CHN = D / 4;
+  return row * (D * 4) + ((ch ^ (row & (CHN >= 8 ? 7 : CHN - 1))) << 4);
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
+  constexpr int CHN = D / 4;   // 16-byte chunks per vector
+  constexpr int NJ = D / 16;   // 16-k groups (also 16-wide d blocks)
+  constexpr int YT = 64;       // streamed vectors per LDS tile
+  __shared__ __attribute__((aligned(16))) char ytile[YT * D * 4];
+  __shared__ __attribute__((aligned(16))) float yn[YT];
+  __shared__ float ymax[YT], yinv[YT];
+  __shared__ int ytgt[YT];
+  __shared__ float tr[MODE == 1 ? 256 : 1][MODE == 1 ? D + 1 : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, i = lane & 15;
+  const int x0 = blockIdx.x * 256 + wave * 64;
+  const int y_begin = blockIdx.y * a.chunk;
+  const int y_end = min(a.NY, y_begin + a.chunk);
+  const float gscale = MODE == 1 ? (*a.gsc) * a.gmul : 0.f;
+
+  // ---- stationary fragments: lane (g,i) of tile t holds X[x0+16t+i][4g+16jj .. +3]
+  uint4 xf[4][NJ];
+  float xn[4], xmax[4], xinv[4];
+  int xtgt[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int x = x0 + t * 16 + i;
+    const bool ok = x < a.NX;
+    float nrm = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (ok) u = *(const uint4*)(a.X + (int64_t)x * D + 4 * g + 16 * jj);
+      xf[t][jj] = u;
+      const float f0 = __uint_as_float(u.x), f1 = __uint_as_float(u.y), f2 = __uint_as_float(u.z), f3 = __uint_as_float(u.w);
+      nrm += f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3;
+    }
+    nrm += __shfl_xor(nrm, 16, 64);
+    nrm += __shfl_xor(nrm, 32, 64);
+    xn[t] = nrm;
+    xmax[t] = 0.f;
+    xinv[t] = 0.f;
+    xtgt[t] = -1;
+    if (a.x_is_query) {
+      if (ok) {
+        const int64_t tg = a.idx[x] - a.row0;
+        xtgt[t] = (tg >= 0 && tg < a.NY) ? (int)tg : -1;
+        if (MODE == 1) {
+          xmax[t] = a.rmax[x];
+          xinv[t] = 1.f / a.rsum[x];
+        }
+      }
+    } else {
+      xtgt[t] = ok ? x : -2;  // table row index: a streamed query hits it when its target == x
+    }
+  }
+
+  float m[4], ssum[4], wsum[4];
+  f32x4 gacc[4][NJ];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    m[t] = -INFINITY;
+    ssum[t] = 0.f;
+    wsum[t] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) gacc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- stream Y in tiles of 64 vectors
+  constexpr int LOADS = YT * CHN / 256;  // 16-byte chunks per thread per tile (2 for D=32)
+  uint4 st[LOADS];
+  auto issue = [&](int y0) {
+#pragma unroll
+    for (int p = 0; p < LOADS; ++p) {
+      const int id = tid + p * 256;
+      const int row = id / CHN, ch = id % CHN;
+      const int y = y0 + row;
+      st[p] = (y < y_end) ? *(const uint4*)(a.Y + (int64_t)y * D + ch * 4) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (y_begin < y_end) issue(y_begin);
+  for (int y0 = y_begin; y0 < y_end; y0 += YT) {
+#pragma unroll
+    for (int p = 0; p < LOADS; ++p) {
+      const int id = tid + p * 256;
+      *(uint4*)(ytile + yoff<D>(id / CHN, id % CHN)) = st[p];
+    }
+    __syncthreads();
+    if (y0 + YT < y_end) issue(y0 + YT);
+    // per-y scalars: norm (4 lanes per vector), and for streamed queries their (max, 1/sum, target)
+    {
+      const int row = tid >> 2, part = tid & 3;  // 64 rows x 4 lanes
+      float nrm = 0.f;
+#pragma unroll
+      for (int c4 = part; c4 < CHN; c4 += 4) {
+        const uint4 u = *(const uint4*)(ytile + yoff<D>(row, c4));
+        const float f0 = __uint_as_float(u.x), f1 = __uint_as_float(u.y), f2 = __uint_as_float(u.z), f3 = __uint_as_float(u.w);
+        nrm += f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3;
+      }
+      nrm += __shfl_xor(nrm, 1, 64);
+      nrm += __shfl_xor(nrm, 2, 64);
+      if (part == 0) {
+        yn[row] = nrm;
+        const int y = y0 + row;
+        if (!a.x_is_query) {
+          const bool ok = y < y_end;
+          ymax[row] = ok && MODE == 1 ? a.rmax[y] : 0.f;
+          yinv[row] = ok && MODE == 1 ? 1.f / a.rsum[y] : 0.f;
+          int tg = -3;
+          if (ok) {
+            const int64_t v = a.idx[y] - a.row0;
+            tg = (v >= 0 && v < a.NX) ? (int)v : -3;
+          }
+          ytgt[row] = tg;
+        }
+      }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int yb = 0; yb < YT / 16; ++yb) {
+      if (y0 + yb * 16 >= y_end) break;
+      // A fragments of the logit product: Y[yb*16+i][4g+16jj .. +3]
+      uint4 af[NJ];
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) af[jj] = *(const uint4*)(ytile + yoff<D>(yb * 16 + i, g + 4 * jj));
+      const float4 ynv = *(const float4*)(yn + yb * 16 + 4 * g);
+      const float ynr[4] = {ynv.x, ynv.y, ynv.z, ynv.w};
+      float ymx[4], yiv[4];
+      int ytg[4];
+      if (MODE == 1 && !a.x_is_query) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ymx[r] = ymax[yb * 16 + 4 * g + r];
+          yiv[r] = yinv[yb * 16 + 4 * g + r];
+          ytg[r] = ytgt[yb * 16 + 4 * g + r];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+          const uint4 ua = af[jj], ub = xf[t][jj];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua.x), __uint_as_float(ub.x), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua.y), __uint_as_float(ub.y), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua.z), __uint_as_float(ub.z), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua.w), __uint_as_float(ub.w), acc, 0, 0, 0);
+        }
+        const bool xok = x0 + t * 16 + i < a.NX;
+        float lg[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int y = y0 + yb * 16 + 4 * g + r;
+          lg[r] = (xok && y < y_end) ? 2.f * a.c * acc[r] - a.c * (ynr[r] + xn[t]) : -INFINITY;
+        }
+        if constexpr (MODE == 0) {
+          const float gm = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+          if (gm > m[t]) {
+            ssum[t] *= __expf(m[t] - gm);
+            m[t] = gm;
+          }
+          if (m[t] > -INFINITY) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ssum[t] += __expf(lg[r] - m[t]);
+          }
+        } else {
+          float w[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int yl = y0 + yb * 16 + 4 * g + r;  // global streamed index
+            float p, hit;
+            if (a.x_is_query) {
+              p = __expf(lg[r] - xmax[t]) * xinv[t];
+              hit = (xtgt[t] == yl) ? 1.f : 0.f;
+            } else {
+              p = __expf(lg[r] - ymx[r]) * yiv[r];
+              hit = (ytg[r] == xtgt[t]) ? 1.f : 0.f;
+            }
+            w[r] = (lg[r] > -INFINITY) ? gscale * (p - hit) : 0.f;
+            wsum[t] += w[r];
+          }
+          // G^T[d][x] += sum_y Y[y][d] * w[y][x]: A = Y^T from LDS (lane: d = 16*dj + i, y = 4g + r), B = w[r]
+#pragma unroll
+          for (int dj = 0; dj < NJ; ++dj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = yb * 16 + 4 * g + r, d = dj * 16 + i;
+              const float av = *(const float*)(ytile + yoff<D>(row, d >> 2) + (d & 3) * 4);
+              gacc[t][dj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[r], gacc[t][dj], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if constexpr (MODE == 0) {
+    // merge the 4 lane groups that share a stationary vector, then one partial per (chunk, x)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float mm = m[t], ss = ssum[t];
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float om = __shfl_xor(mm, o, 64), os = __shfl_xor(ss, o, 64);
+        const float nm = fmaxf(mm, om);
+        ss = (nm == -INFINITY) ? 0.f : ss * __expf(mm - nm) + os * __expf(om - nm);
+        mm = nm;
+      }
+      const int x = x0 + t * 16 + i;
+      if (g == 0 && x < a.NX) a.part[(int64_t)blockIdx.y * a.NX + x] = make_float2(mm, ss);
+    }
+  } else {
+    // grad_x = 2c (G - X W); lane holds G[x = 16t+i][d = 16dj + 4g + reg]; transpose through LDS -> row-contiguous atomics
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float ws = wsum[t];
+      ws += __shfl_xor(ws, 16, 64);
+      ws += __shfl_xor(ws, 32, 64);
+#pragma unroll
+      for (int dj = 0; dj < NJ; ++dj) {
+        const int x = x0 + t * 16 + i;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x < a.NX) xv = *(const float4*)(a.X + (int64_t)x * D + dj * 16 + 4 * g);
+        const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          tr[wave * 64 + t * 16 + i][dj * 16 + 4 * g + r] = 2.f * a.c * (gacc[t][dj][r] - xr[r] * ws);
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < 256 * D; e += 256) {
+      const int rr = e / D, d = e % D;
+      const int x = blockIdx.x * 256 + rr;
+      if (x < a.NX) atomicAdd(a.G + (int64_t)x * D + d, tr[rr][d]);
+    }
+  }
+}
+
+static inline int mfma_chunk(int64_t nx, int64_t ny) {
+  const int64_t xt = fh_cdiv(nx, 256);
+  int64_t want = fh_cdiv(1024, xt);
+  int64_t chunk = fh_cdiv(fh_cdiv(ny, want), 64) * 64;
+  if (chunk < 64) chunk = 64;
+  return (int)chunk;
+}
+
+// host-side entry points used by loss.hip
+bool disc_mfma_supported(int64_t B, int64_t S, int64_t D) { return D == 32 && B * S >= (int64_t)1 << 16; }
+
+int64_t disc_mfma_ws_bytes(int64_t B, int64_t S) {
+  const int chunk = mfma_chunk(B, S);
+  return fh_cdiv(S, chunk) * B * (int64_t)sizeof(float2);
+}
+
+int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
+                  int64_t B, int64_t S, hipStream_t st) {
+  DiscMfmaArgs a = {};
+  a.X = q;
+  a.Y = table;
+  a.NX = (int)B;
+  a.NY = (int)S;
+  a.c = c;
+  a.x_is_query = 1;
+  a.idx = idx;
+  a.row0 = row0;
+  a.part = part;
+  a.chunk = mfma_chunk(B, S);
+  *nchunks = (int)fh_cdiv(S, a.chunk);
+  dim3 grid((unsigned)fh_cdiv(B, 256), (unsigned)*nchunks);
+  hipLaunchKernelGGL((disc_mfma_kernel<32, 0>), grid, dim3(256), 0, st, a);
+  return fh_launch_status();
+}
+
+int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
+                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, int64_t B, int64_t S,
+                  hipStream_t st) {
+  DiscMfmaArgs a = {};
+  a.c = c;
+  a.idx = idx;
+  a.row0 = row0;
+  a.rmax = rmax;
+  a.rsum = rsum;
+  a.gsc = gsc;
+  a.gmul = gmul;
+  if (dq) {  // stationary = queries, streamed = table rows
+    a.X = q;
+    a.Y = table;
+    a.NX = (int)B;
+    a.NY = (int)S;
+    a.x_is_query = 1;
+    a.G = dq;
+    a.chunk = mfma_chunk(B, S);
+    dim3 grid((unsigned)fh_cdiv(B, 256), (unsigned)fh_cdiv(S, a.chunk));
+    hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
+    int e = fh_launch_status();
+    if (e) return e;
+  }
+  if (dtable) {  // stationary = table rows, streamed = queries
+    a.X = table;
+    a.Y = q;
+    a.NX = (int)S;
+    a.NY = (int)B;
+    a.x_is_query = 0;
+    a.G = dtable;
+    a.chunk = mfma_chunk(S, B);
+    dim3 grid((unsigned)fh_cdiv(S, 256), (unsigned)fh_cdiv(B, a.chunk));
+    hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
+    int e = fh_launch_status();
+    if (e) return e;
+  }
+  return FHVAE_OK;
+}
+
+}  // namespace fh

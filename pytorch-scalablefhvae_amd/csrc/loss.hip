@@ -3,6 +3,7 @@
 //   log-sum-exp cross-entropy over the mu2 table (:119-122), fused Adam (train_model.py:409-411),
 //   layout utilities.
 #include "common.h"
+#include <cstdlib>
 
 namespace fh {
 
@@ -534,10 +535,21 @@ extern "C" int fhvae_elbo_bwd(const fhvae_elbo_bwd_desc* d, void* stream) {
   return fh_launch_status();
 }
 
+namespace fh {  // disc_mfma.hip: the matrix-core form for large (B x S), D == 32
+bool disc_mfma_supported(int64_t B, int64_t S, int64_t D);
+int64_t disc_mfma_ws_bytes(int64_t B, int64_t S);
+int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
+                  int64_t B, int64_t S, hipStream_t st);
+int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
+                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, int64_t B, int64_t S,
+                  hipStream_t st);
+}  // namespace fh
+
 extern "C" int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S) {
   if (B <= 0 || S <= 0) return 0;
   DiscPlan p = disc_plan(B, S);
-  return (int64_t)p.nchunks * B * (int64_t)sizeof(float2);
+  const int64_t a = (int64_t)p.nchunks * B * (int64_t)sizeof(float2), b = disc_mfma_ws_bytes(B, S);
+  return a > b ? a : b;
 }
 
 #define DISC_DISPATCH(D_, CALL) \
@@ -567,10 +579,15 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
   hipStream_t st = (hipStream_t)stream;
   DiscPlan p = disc_plan(B, S);
   float2* part = (float2*)ws;
-  dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
-  DISC_DISPATCH(D, hipLaunchKernelGGL((disc_fwd_kernel<DD>), grid, dim3(256), 0, st, q, table, inv_two_var, part, (int)B,
-                                      (int)S, p.chunk));
-  int e = fh_launch_status();
+  int e;
+  if (disc_mfma_supported(B, S, D) && !getenv("FHVAE_DISC_VALU")) {
+    e = disc_mfma_fwd(q, table, idx, row0, inv_two_var, part, &p.nchunks, B, S, st);
+  } else {
+    dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
+    DISC_DISPATCH(D, hipLaunchKernelGGL((disc_fwd_kernel<DD>), grid, dim3(256), 0, st, q, table, inv_two_var, part, (int)B,
+                                        (int)S, p.chunk));
+    e = fh_launch_status();
+  }
   if (e) return e;
   DISC_DISPATCH(D, hipLaunchKernelGGL((disc_combine_kernel<DD>), dim3((unsigned)fh_cdiv(B, 4)), dim3(256), 0, st, q, table, idx,
                                       row0, inv_two_var, part, p.nchunks, row_max, row_sumexp, tgt_logit, (int)B, (int)S));
@@ -623,6 +640,13 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
   FH_CHECK_I32(S);
   (void)ws;
   hipStream_t st = (hipStream_t)stream;
+  if (disc_mfma_supported(B, S, D) && !getenv("FHVAE_DISC_VALU")) {
+    if (dq) {
+      hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
+      if (he != hipSuccess) return (int)he;
+    }
+    return disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, B, S, st);
+  }
   if (dq) {
     hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
     if (he != hipSuccess) return (int)he;

@@ -203,7 +203,7 @@ def test_disc_lse_golden(hb, golden_dir, name):
 
 
 @pytest.mark.parametrize("B,S,D,spread", [(3, 5, 4, 1.0), (300, 1000, 32, 1.0), (257, 777, 16, 6.0), (64, 9, 8, 3.0),
-                                          (2048, 4600, 32, 1.0)])
+                                          (2048, 4600, 32, 1.0), (513, 3001, 32, 4.0), (70, 1000, 32, 0.3)])
 def test_disc_lse_vs_oracle(hb, B, S, D, spread):
     torch.manual_seed(B + S)
     q = (torch.randn(B, D) * spread).requires_grad_(True)
