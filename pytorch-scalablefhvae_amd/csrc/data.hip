@@ -8,24 +8,43 @@
 
 namespace fh {
 
-// one thread = one float4 (or one element) of the output; output batch-major (B,T,F) and/or time-major (T,B,F)
+// one thread = V consecutive features of one output frame (V = 4: 16-byte accesses when F % 4 == 0); output
+// batch-major (B,T,F) and/or time-major (T,B,F)
+template <int V>
 __global__ void segment_gather_kernel(const float* __restrict__ pool, const int64_t* __restrict__ start,
                                       const float* __restrict__ mean, const float* __restrict__ inv_std,
                                       float* __restrict__ out_btf, float* __restrict__ out_tbf, int64_t B, int64_t T_,
                                       int64_t F, int64_t pool_frames, int32_t* oob) {
+  const int64_t FV = F / V;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * T_ * F) return;
-  const int64_t f = i % F, t = (i / F) % T_, b = i / (F * T_);
+  if (i >= B * T_ * FV) return;
+  const int64_t f = (i % FV) * V, t = (i / FV) % T_, b = i / (FV * T_);
   const int64_t fr = start[b] + t;
-  float v = 0.f;
+  float v[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) v[e] = 0.f;
   if (fr >= 0 && fr < pool_frames) {
-    v = pool[fr * F + f];
-    if (mean) v = (v - mean[f]) * inv_std[f];
+    if constexpr (V == 4) {
+      const float4 u = *(const float4*)(pool + fr * F + f);
+      v[0] = u.x, v[1] = u.y, v[2] = u.z, v[3] = u.w;
+    } else {
+      v[0] = pool[fr * F + f];
+    }
+    if (mean) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = (v[e] - mean[f + e]) * inv_std[f + e];
+    }
   } else if (oob && f == 0) {
     atomicOr(oob, 1);
   }
-  if (out_btf) out_btf[i] = v;
-  if (out_tbf) out_tbf[(t * B + b) * F + f] = v;
+  const int64_t o1 = (b * T_ + t) * F + f, o2 = (t * B + b) * F + f;
+  if constexpr (V == 4) {
+    if (out_btf) *(float4*)(out_btf + o1) = make_float4(v[0], v[1], v[2], v[3]);
+    if (out_tbf) *(float4*)(out_tbf + o2) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    if (out_btf) out_btf[o1] = v[0];
+    if (out_tbf) out_tbf[o2] = v[0];
+  }
 }
 
 __global__ void mu2_accum_kernel(const float* __restrict__ z, const int64_t* __restrict__ idx, float* __restrict__ zsum,
@@ -62,9 +81,16 @@ extern "C" int fhvae_segment_gather(const float* pool, int64_t pool_frames, cons
   FH_CHECK_POS(B);
   FH_CHECK_POS(T);
   FH_CHECK_POS(F);
-  const int64_t n = B * T * F;
-  hipLaunchKernelGGL(segment_gather_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pool, start,
-                     mean, inv_std, out_btf, out_tbf, B, T, F, pool_frames, oob_flag);
+  const bool vec = F % 4 == 0 && ((((uintptr_t)pool | (uintptr_t)out_btf | (uintptr_t)out_tbf) & 15) == 0);
+  if (vec) {
+    const int64_t n = B * T * (F / 4);
+    hipLaunchKernelGGL(segment_gather_kernel<4>, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pool, start,
+                       mean, inv_std, out_btf, out_tbf, B, T, F, pool_frames, oob_flag);
+  } else {
+    const int64_t n = B * T * F;
+    hipLaunchKernelGGL(segment_gather_kernel<1>, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pool, start,
+                       mean, inv_std, out_btf, out_tbf, B, T, F, pool_frames, oob_flag);
+  }
   return fh_launch_status();
 }
 

@@ -146,14 +146,50 @@ __global__ __launch_bounds__(256) void elbo_bwd_kernel(fhvae_elbo_bwd_desc bd) {
     const float* xl = d.x_lv + b * d.xo_sb;
     float* dm = bd.d_x_mu + b * d.xo_sb;
     float* dl = bd.d_x_lv + b * d.xo_sb;
-    const int n = (int)(d.T * d.F);
-    for (int i = lane; i < n; i += 64) {
-      const int t = i / (int)d.F, f = i % (int)d.F;
-      const int64_t o = t * d.xo_st + f;
-      const float df = x[t * d.x_st + f] - xm[o];
-      const float iv = 1.f / expf(xl[o]);
-      dm[o] = gpx * df * iv;
-      dl[o] = gpx * -0.5f * (1.f - df * df * iv);
+    const bool vec = (d.F % 4 == 0) && (d.x_sb % 4 == 0) && (d.x_st % 4 == 0) && (d.xo_sb % 4 == 0) && (d.xo_st % 4 == 0) &&
+                     ((((uintptr_t)d.x | (uintptr_t)d.x_mu | (uintptr_t)d.x_lv | (uintptr_t)bd.d_x_mu | (uintptr_t)bd.d_x_lv) & 15) == 0);
+    if (vec) {
+      const int F4 = (int)(d.F / 4), n4 = (int)d.T * F4;
+      for (int i = lane; i < n4; i += 64) {
+        const int t = i / F4, f = (i % F4) * 4;
+        const int64_t o = t * d.xo_st + f;
+        const float4 a = *(const float4*)(x + t * d.x_st + f);
+        const float4 mu = *(const float4*)(xm + o);
+        const float4 lv = *(const float4*)(xl + o);
+        float4 gm, gl;
+        {
+          const float df = a.x - mu.x, iv = 1.f / expf(lv.x);
+          gm.x = gpx * df * iv;
+          gl.x = gpx * -0.5f * (1.f - df * df * iv);
+        }
+        {
+          const float df = a.y - mu.y, iv = 1.f / expf(lv.y);
+          gm.y = gpx * df * iv;
+          gl.y = gpx * -0.5f * (1.f - df * df * iv);
+        }
+        {
+          const float df = a.z - mu.z, iv = 1.f / expf(lv.z);
+          gm.z = gpx * df * iv;
+          gl.z = gpx * -0.5f * (1.f - df * df * iv);
+        }
+        {
+          const float df = a.w - mu.w, iv = 1.f / expf(lv.w);
+          gm.w = gpx * df * iv;
+          gl.w = gpx * -0.5f * (1.f - df * df * iv);
+        }
+        *(float4*)(dm + o) = gm;
+        *(float4*)(dl + o) = gl;
+      }
+    } else {
+      const int n = (int)(d.T * d.F);
+      for (int i = lane; i < n; i += 64) {
+        const int t = i / (int)d.F, f = i % (int)d.F;
+        const int64_t o = t * d.xo_st + f;
+        const float df = x[t * d.x_st + f] - xm[o];
+        const float iv = 1.f / expf(xl[o]);
+        dm[o] = gpx * df * iv;
+        dl[o] = gpx * -0.5f * (1.f - df * df * iv);
+      }
     }
   }
   const float v2 = expf(kPz2Logvar);
@@ -397,22 +433,55 @@ __global__ __launch_bounds__(256) void disc_bwd_dt_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 // Adam
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v, float lr_bc1, float rs_bc2, float b1,
+                                          float b2, float eps, float gscale) {
+  const float gi = g * gscale;
+  m = b1 * m + (1.f - b1) * gi;
+  v = b2 * v + (1.f - b2) * gi * gi;
+  const float denom = sqrtf(v) * rs_bc2 + eps;
+  p = p - lr_bc1 * (m / denom);
+  return p;
+}
+
+// 16 bytes per lane per stream (the arena is 64-element aligned); scalar tail
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, u16* __restrict__ plp, int64_t n, float lr, float b1, float b2,
                             float eps, float gscale, const int32_t* __restrict__ step) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
   const float t = (float)(*step);
-  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
-  const float gi = g[i] * gscale;
-  const float mi = b1 * m[i] + (1.f - b1) * gi;
-  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-  m[i] = mi;
-  v[i] = vi;
-  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-  const float pi = p[i] - (lr / bc1) * (mi / denom);
-  p[i] = pi;
-  if (plp) plp[i] = f2bf(pi);
+  const float lr_bc1 = lr / (1.f - powf(b1, t)), rs_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
+  const int64_t n4 = n / 4;
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    for (int64_t k = i; k < n4; k += stride) {
+      float4 pp = ((float4*)p)[k], mm = ((float4*)m)[k], vv = ((float4*)v)[k];
+      const float4 gg = ((const float4*)g)[k];
+      adam_one(pp.x, gg.x, mm.x, vv.x, lr_bc1, rs_bc2, b1, b2, eps, gscale);
+      adam_one(pp.y, gg.y, mm.y, vv.y, lr_bc1, rs_bc2, b1, b2, eps, gscale);
+      adam_one(pp.z, gg.z, mm.z, vv.z, lr_bc1, rs_bc2, b1, b2, eps, gscale);
+      adam_one(pp.w, gg.w, mm.w, vv.w, lr_bc1, rs_bc2, b1, b2, eps, gscale);
+      ((float4*)p)[k] = pp;
+      ((float4*)m)[k] = mm;
+      ((float4*)v)[k] = vv;
+      if (plp) {
+        plp[4 * k] = f2bf(pp.x);
+        plp[4 * k + 1] = f2bf(pp.y);
+        plp[4 * k + 2] = f2bf(pp.z);
+        plp[4 * k + 3] = f2bf(pp.w);
+      }
+    }
+    i += n4 * 4;  // tail elements
+    for (int64_t k = i; k < n; k += stride) {
+      const float r = adam_one(p[k], g[k], m[k], v[k], lr_bc1, rs_bc2, b1, b2, eps, gscale);
+      if (plp) plp[k] = f2bf(r);
+    }
+  } else {
+    for (int64_t k = i; k < n; k += stride) {
+      const float r = adam_one(p[k], g[k], m[k], v[k], lr_bc1, rs_bc2, b1, b2, eps, gscale);
+      if (plp) plp[k] = f2bf(r);
+    }
+  }
 }
 
 }  // namespace fh
@@ -676,7 +745,10 @@ extern "C" int fhvae_adam_step(float* p, const float* g, float* m, float* v, voi
   FH_CHECK_PTR(v);
   FH_CHECK_PTR(step_count);
   FH_CHECK_POS(n);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (u16*)p_lp, n, lr, beta1, beta2, eps, grad_scale, step_count);
+  int64_t blocks = fh_cdiv(fh_cdiv(n, 4), 256);
+  if (blocks > 8192) blocks = 8192;  // grid-stride beyond that
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (u16*)p_lp, n, lr,
+                     beta1, beta2, eps, grad_scale, step_count);
   return fh_launch_status();
 }
