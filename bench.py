@@ -25,6 +25,8 @@ for _p in (ROOT, PKG):
 import torch
 
 CONFIGS = {
+    # configs[0]: the reference's own runnable model (FC SimpleFHVAE; "1-layer LSTM" has no referent) on the HIP path
+    "c1": dict(H=128, L=2, D=32, S=100, T=20, F=80, B=250, simple=True, desc="simple_fhvae.SimpleFHVAE 128/128 FC, z1=z2=32, 100-seq mu2 table"),
     # name: (H, layers, D, S, T, F, default per-GPU batch)
     "c2": dict(H=256, L=2, D=32, S=4600, T=20, F=80, B=256, desc="fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 4.6k-seq mu2 table"),
     "c3": dict(H=256, L=2, D=32, S=28000, T=20, F=80, B=2048, desc="same model, 28k-seq mu2 table, batch 2048"),
@@ -59,7 +61,8 @@ def cpu_baseline(cfg, B, budget_s=20.0):
 
     H, L, D, S, T, F = (cfg[k] for k in "HLDSTF")
     torch.manual_seed(0)
-    m = R.FHVAERef(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T)
+    m = (R.SimpleFHVAERef(T * F, [H] * L, [H] * L, D, D, [H] * L) if cfg.get("simple")
+         else R.FHVAERef(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T))
     table = torch.randn(S, D, requires_grad=True)
     opt = torch.optim.Adam(list(m.parameters()) + [table], lr=1e-3, betas=(0.95, 0.999))
     x = torch.randn(B, T, F)
@@ -75,7 +78,8 @@ def cpu_baseline(cfg, B, budget_s=20.0):
             break
     dt = time.time() - t0
     return {"value": B * n / dt, "unit": "segments/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full training steps (fwd+loss+bwd+Adam) of the torch-CPU oracle FHVAERef at B=%d, S=%d, fp32" % (n, B, S)}
+            "sample": "%d full training steps (fwd+loss+bwd+Adam) of the torch-CPU oracle %s at B=%d, S=%d, fp32"
+                      % (n, type(m).__name__, B, S)}
 
 
 def main():
@@ -120,8 +124,14 @@ def main():
     B = args.batch or cfg["B"]
     H, L, D, S, T, F = (cfg[k] for k in "HLDSTF")
     torch.manual_seed(0)
-    model = FHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T, num_seqs=S, reference_compat=False,
-                  compute_dtype=args.dtype).to(device)
+    if cfg.get("simple"):
+        from simple_fhvae import SimpleFHVAE
+
+        model = SimpleFHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, num_seqs=S, reference_compat=False).to(device)
+        args.dtype = "f32"
+    else:
+        model = FHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T, num_seqs=S, reference_compat=False,
+                      compute_dtype=args.dtype).to(device)
     with torch.no_grad():
         model.mu2_table.copy_(torch.randn(S, D, generator=torch.Generator().manual_seed(1)))
     if use_dist:
@@ -156,6 +166,7 @@ def main():
     use_graph = not args.no_graph and runner is None
     eager_step = step
     if use_graph:
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)  # capture runs on a side stream by design
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -207,6 +218,8 @@ def main():
         per_op = hb.OP_TIMER.summary()
         hb.OP_TIMER.disable()
         names = {0: "lstm_fwd_step_kernel", 1: "lstm_bwd_step_kernel"}
+        if not cells:  # FC model: no LSTM cells to trace
+            cells = {0: (1, 1e-9, 0.0)}
         dom = max(cells, key=lambda k: cells[k][1])
         n, t_ms, fl = cells[dom]
         ach = fl / (t_ms * 1e-3) / 1e12

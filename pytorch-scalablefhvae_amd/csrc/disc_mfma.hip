@@ -289,7 +289,7 @@ static inline int mfma_chunk(int64_t nx, int64_t ny) {
 }
 
 // host-side entry points used by loss.hip
-bool disc_mfma_supported(int64_t B, int64_t S, int64_t D) { return D == 32 && B * S >= (int64_t)1 << 16; }
+bool disc_mfma_supported(int64_t B, int64_t S, int64_t D) { return (D == 32 || D == 16) && B * S >= (int64_t)1 << 16; }
 
 int64_t disc_mfma_ws_bytes(int64_t B, int64_t S) {
   const int chunk = mfma_chunk(B, S);
@@ -297,7 +297,7 @@ int64_t disc_mfma_ws_bytes(int64_t B, int64_t S) {
 }
 
 int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
-                  int64_t B, int64_t S, hipStream_t st) {
+                  int64_t B, int64_t S, int64_t D, hipStream_t st) {
   DiscMfmaArgs a = {};
   a.X = q;
   a.Y = table;
@@ -311,13 +311,16 @@ int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_
   a.chunk = mfma_chunk(B, S);
   *nchunks = (int)fh_cdiv(S, a.chunk);
   dim3 grid((unsigned)fh_cdiv(B, 256), (unsigned)*nchunks);
-  hipLaunchKernelGGL((disc_mfma_kernel<32, 0>), grid, dim3(256), 0, st, a);
+  if (D == 32)
+    hipLaunchKernelGGL((disc_mfma_kernel<32, 0>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((disc_mfma_kernel<16, 0>), grid, dim3(256), 0, st, a);
   return fh_launch_status();
 }
 
 int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
                   const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, int64_t B, int64_t S,
-                  hipStream_t st) {
+                  int64_t D, hipStream_t st) {
   DiscMfmaArgs a = {};
   a.c = c;
   a.idx = idx;
@@ -335,7 +338,10 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
     a.G = dq;
     a.chunk = mfma_chunk(B, S);
     dim3 grid((unsigned)fh_cdiv(B, 256), (unsigned)fh_cdiv(S, a.chunk));
-    hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
+    if (D == 32)
+      hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((disc_mfma_kernel<16, 1>), grid, dim3(256), 0, st, a);
     int e = fh_launch_status();
     if (e) return e;
   }
@@ -348,7 +354,10 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
     a.G = dtable;
     a.chunk = mfma_chunk(S, B);
     dim3 grid((unsigned)fh_cdiv(S, 256), (unsigned)fh_cdiv(B, a.chunk));
-    hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
+    if (D == 32)
+      hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((disc_mfma_kernel<16, 1>), grid, dim3(256), 0, st, a);
     int e = fh_launch_status();
     if (e) return e;
   }

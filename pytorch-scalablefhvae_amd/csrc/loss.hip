@@ -608,10 +608,10 @@ namespace fh {  // disc_mfma.hip: the matrix-core form for large (B x S), D == 3
 bool disc_mfma_supported(int64_t B, int64_t S, int64_t D);
 int64_t disc_mfma_ws_bytes(int64_t B, int64_t S);
 int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
-                  int64_t B, int64_t S, hipStream_t st);
+                  int64_t B, int64_t S, int64_t D, hipStream_t st);
 int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
                   const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, int64_t B, int64_t S,
-                  hipStream_t st);
+                  int64_t D, hipStream_t st);
 }  // namespace fh
 
 extern "C" int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S) {
@@ -650,7 +650,7 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
   float2* part = (float2*)ws;
   int e;
   if (disc_mfma_supported(B, S, D) && !getenv("FHVAE_DISC_VALU")) {
-    e = disc_mfma_fwd(q, table, idx, row0, inv_two_var, part, &p.nchunks, B, S, st);
+    e = disc_mfma_fwd(q, table, idx, row0, inv_two_var, part, &p.nchunks, B, S, D, st);
   } else {
     dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
     DISC_DISPATCH(D, hipLaunchKernelGGL((disc_fwd_kernel<DD>), grid, dim3(256), 0, st, q, table, inv_two_var, part, (int)B,
@@ -714,7 +714,7 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
       hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
       if (he != hipSuccess) return (int)he;
     }
-    return disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, B, S, st);
+    return disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, B, S, D, st);
   }
   if (dq) {
     hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
