@@ -67,15 +67,39 @@ class ShardCtx:
         self.is_gloo = dist.get_backend(group) == "gloo"
 
     # -- collectives over dim 0, equal sizes on every rank --------------------------------------
+    # RCCL ("nccl") is the product transport.  With a gloo group (CPU tests; two ranks sharing one GPU in the GPU
+    # test) device tensors are staged through the host, which only changes the transport, not the arithmetic.
+    def _staged(self, t):
+        return self.is_gloo and t.is_cuda
+
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
+        if self._staged(x):
+            return self.all_gather(x.cpu()).to(x.device)
         out = x.new_empty((self.world * x.shape[0],) + tuple(x.shape[1:]))
         dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
         return out
 
+    def all_reduce_(self, t: torch.Tensor, op=None, async_op=False):
+        op = op if op is not None else dist.ReduceOp.SUM
+        if self._staged(t):
+            c = t.cpu()
+            dist.all_reduce(c, op=op, group=self.group)
+            t.copy_(c)
+            return None
+        return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
+
+    def broadcast_(self, t: torch.Tensor, src=0):
+        if self._staged(t):
+            c = t.cpu()
+            dist.broadcast(c, src, group=self.group)
+            t.copy_(c)
+        else:
+            dist.broadcast(t, src, group=self.group)
+
     def reduce_scatter(self, x_all: torch.Tensor) -> torch.Tensor:
         n = x_all.shape[0] // self.world
         if self.is_gloo:  # gloo has no reduce_scatter: all-reduce and keep the own slice
-            dist.all_reduce(x_all, group=self.group)
+            self.all_reduce_(x_all)
             return x_all[self.rank * n:(self.rank + 1) * n].clone()
         out = x_all.new_empty((n,) + tuple(x_all.shape[1:]))
         dist.reduce_scatter_tensor(out, x_all.contiguous(), group=self.group)
@@ -115,9 +139,9 @@ class _ShardDisc(torch.autograd.Function):
         q_all = sh.all_gather(q_local.detach())
         rmax, rsum, tgt = be.disc_partials(q_all, shard, idx_all, sh.row0)
         m = rmax.clone()
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=sh.group)
+        sh.all_reduce_(m, op=dist.ReduceOp.MAX)
         st = torch.stack([be.disc_rescale(rmax, rsum, m), tgt])
-        dist.all_reduce(st, group=sh.group)
+        sh.all_reduce_(st)
         ce = be.ce_mean(m, st[0].contiguous(), st[1].contiguous())
         ctx.sh = sh
         ctx.save_for_backward(q_all, shard, idx_all, m, st[0].contiguous())
@@ -188,7 +212,7 @@ class DistributedFHVAE:
         nets = [p for g in (0, 1, 2) for n, p in named if group_of(n) == g]
         counts = [sum(1 for n, _ in named if group_of(n) == g) for g in (0, 1, 2)]
         for p in nets:  # replicas start identical
-            dist.broadcast(p.data, 0, group=group)
+            self.sh.broadcast_(p.data, 0)
         self.opt_nets = FusedAdam(nets, lr=lr, betas=betas, eps=eps, grad_scale=1.0 / self.sh.world)
         self.opt_table = FusedAdam([self.shard], lr=lr, betas=betas, eps=eps, grad_scale=1.0)
         offs = self.opt_nets.g_arena.offsets + [self.opt_nets.g_arena.numel]
@@ -215,15 +239,17 @@ class DistributedFHVAE:
         if g is None or g in self._pending:
             return
         b, e = self._buckets[g]
-        self._pending[g] = dist.all_reduce(self.opt_nets.g_arena.flat[b:e], group=self.sh.group, async_op=True)
+        h = self.sh.all_reduce_(self.opt_nets.g_arena.flat[b:e], async_op=True)
+        self._pending[g] = h  # None when the transport was synchronous (staged gloo)
 
     def _reduce_gradients(self):
         flat = self.opt_nets.flat_grad()
         for g, (b, e) in enumerate(self._buckets):
             if g in self._pending:
-                self._pending[g].wait()
+                if self._pending[g] is not None:
+                    self._pending[g].wait()
             elif e > b:
-                dist.all_reduce(flat[b:e], group=self.sh.group)
+                self.sh.all_reduce_(flat[b:e])
         self._pending.clear()
 
     def train_step(self, x, idx, nsegs, alpha=10.0):

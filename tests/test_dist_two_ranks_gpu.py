@@ -1,0 +1,81 @@
+"""Two ranks sharing ONE MI355X (gloo transport staged through the host; the kernels, the sharded-table ops, the
+gradient buckets and both fused-Adam arenas are the product code): the data-parallel + row-sharded run must reproduce
+the single-process run on the global batch."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+T, F, H, D, BL, S = 20, 80, 32, 16, 24, 37  # S odd: ragged last shard
+
+
+def _data(world):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(world * BL, T, F, generator=g)
+    idx = torch.randint(0, S, (world * BL,), generator=g)
+    idx[1] = idx[BL]  # the same sequence on both ranks
+    ns = torch.randint(20, 200, (world * BL,), generator=g)
+    e2, e1 = torch.randn(world * BL, D, generator=g), torch.randn(world * BL, D, generator=g)
+    return x, idx, ns, e2, e1
+
+
+def _build():
+    from fhvae import FHVAE
+
+    torch.manual_seed(11)
+    return FHVAE(T * F, [H, H], [H, H], D, D, [H, H], num_seqs=S, reference_compat=False).cuda()
+
+
+def _worker(rank, world, port, ret):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "pytorch-scalablefhvae_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dist_shard import DistributedFHVAE
+
+    x, idx, ns, e2, e1 = _data(world)
+    sl = slice(rank * BL, (rank + 1) * BL)
+    m = _build()
+    runner = DistributedFHVAE(m, lr=1e-3, betas=(0.95, 0.999))
+    fwd = m.forward
+    m.forward = lambda *a, **k: fwd(*a, eps=(e2[sl].cuda(), e1[sl].cuda()), **k)
+    losses = [runner.train_step(x[sl].cuda(), idx[sl].cuda(), ns[sl].cuda(), alpha=10.0)[0].item() for _ in range(3)]
+    ret[rank] = dict(losses=losses, rows=(runner.sh.row0, runner.sh.row1), shard=runner.shard.detach().cpu(),
+                     w=m.z2_pre_encoder.lstm.weight_hh_l1.detach().cpu(), wd=m.pre_decoder.lstm.weight_ih_l0.detach().cpu())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_single_process_global_batch():
+    from hip_optim import FusedAdam
+    from train_model import loss_function
+
+    world = 2
+    x, idx, ns, e2, e1 = _data(world)
+    m = _build()
+    opt = FusedAdam(m.parameters(), lr=1e-3, betas=(0.95, 0.999))
+    ref_losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = m(x.cuda(), idx, S, ns, eps=(e2, e1))
+        loss = loss_function(out[0], out[1], 10.0)
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, 29700 + os.getpid() % 200, ret), nprocs=world, join=True)
+    assert ret[0]["rows"] == (0, 19) and ret[1]["rows"] == (19, 37)
+    for k in range(3):  # global loss = mean of the two local losses (equal local batch sizes)
+        got = 0.5 * (ret[0]["losses"][k] + ret[1]["losses"][k])
+        assert abs(got - ref_losses[k]) <= 2e-4 * abs(ref_losses[k]), (k, got, ref_losses[k])
+    table = m.mu2_table.detach().cpu()
+    for r in range(world):
+        a, b = ret[r]["rows"]
+        torch.testing.assert_close(ret[r]["shard"], table[a:b], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(ret[r]["w"], m.z2_pre_encoder.lstm.weight_hh_l1.detach().cpu(), rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(ret[r]["wd"], m.pre_decoder.lstm.weight_ih_l0.detach().cpu(), rtol=2e-4, atol=2e-5)
