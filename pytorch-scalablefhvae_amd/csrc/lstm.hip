@@ -89,7 +89,9 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
   __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
   const FwdJob<T>& J = jobs.job[blockIdx.z];
   const int B = jobs.B, H = jobs.H;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // blockIdx.x walks the ROW tiles: workgroups are dealt round-robin over the 8 XCDs by linear id, so every XCD
+  // (private 4 MB L2) sees 1/8 of the activations and all of the (small) weight slice, instead of all activations
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   f32x4 acc[TM][4];
   zero_acc(acc);
   RowIdent arm{B};
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
     }
   }
   const int nkb = num_kblocks<T, CH>(J.seg);
-  mainloop<T, BM, BN, WM, WN, CH, true, true>(acc, J.seg, m0, B, n0, (int)gridDim.x * BN, arm, brm, 0, nkb, smem);
+  mainloop<T, BM, BN, WM, WN, CH, true, true>(acc, J.seg, m0, B, n0, (int)gridDim.y * BN, arm, brm, 0, nkb, smem);
 
   if (!uok) return;
 #pragma unroll
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
   __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
   const BwdJob<T>& J = jobs.job[blockIdx.z];
   const int B = jobs.B, H = jobs.H;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // row tiles on x: XCD-local activations (see the forward cell)
   f32x4 acc[TM][TN];
   zero_acc(acc);
   RowIdent arm{B}, brm{H};
@@ -439,14 +441,14 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     for (int j = 0; j < nj; ++j) fl += 2.0 * B * 4 * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
     const int ts = trace_begin(st, kTraceFwdCell, fl);
     if (B >= 16384) {  // large tiles only pay once they still give >= 2 workgroups per CU (see gemm.hip)
-      dim3 grid((unsigned)fh_cdiv(H, 32), (unsigned)fh_cdiv(B, 128), (unsigned)nj);
+      dim3 grid((unsigned)fh_cdiv(B, 128), (unsigned)fh_cdiv(H, 32), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 128, 128, 2, 2, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else if (B >= 1024) {
       // many workgroups per CU: 256-byte panels (32 KB LDS) so 2 workgroups per CU keep twice the bytes in flight
-      dim3 grid((unsigned)fh_cdiv(H, 16), (unsigned)fh_cdiv(B, 64), (unsigned)nj);
+      dim3 grid((unsigned)fh_cdiv(B, 64), (unsigned)fh_cdiv(H, 16), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 64, 64, 4, 1, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else {
-      dim3 grid((unsigned)fh_cdiv(H, 16), (unsigned)fh_cdiv(B, 64), (unsigned)nj);
+      dim3 grid((unsigned)fh_cdiv(B, 64), (unsigned)fh_cdiv(H, 16), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 64, 64, 4, 1, kCH>), grid, dim3(kThreads), 0, st, jobs);
     }
     trace_end(st, ts);
@@ -515,13 +517,13 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     for (int j = 0; j < nj; ++j) fl += 2.0 * B * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
     const int ts = trace_begin(st, kTraceBwdCell, fl);
     if (B >= 16384) {
-      dim3 grid((unsigned)fh_cdiv(H, 64), (unsigned)fh_cdiv(B, 128), (unsigned)nj);
+      dim3 grid((unsigned)fh_cdiv(B, 128), (unsigned)fh_cdiv(H, 64), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 128, 64, 4, 1, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else if (B >= 1024) {
-      dim3 grid((unsigned)fh_cdiv(H, 32), (unsigned)fh_cdiv(B, 32), (unsigned)nj);
+      dim3 grid((unsigned)fh_cdiv(B, 32), (unsigned)fh_cdiv(H, 32), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 32, 32, 2, 2, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else {
-      dim3 grid((unsigned)fh_cdiv(H, 32), (unsigned)fh_cdiv(B, 32), (unsigned)nj);
+      dim3 grid((unsigned)fh_cdiv(B, 32), (unsigned)fh_cdiv(H, 32), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 32, 32, 2, 2, kCH>), grid, dim3(kThreads), 0, st, jobs);
     }
     trace_end(st, ts);
