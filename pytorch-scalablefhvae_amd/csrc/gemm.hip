@@ -28,13 +28,29 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   using TL = Tile<T, BM, BN, WM, WN, CH>;
   constexpr int TM = TL::TM, TN = TL::TN;
   __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order (guide T1, bijective form): workgroups are dealt round-robin over the 8 XCDs by linear id;
+  // remap so that each XCD owns a CONTIGUOUS range of logical tiles (x fastest, then y, then the K slice): tiles that
+  // share an operand panel then share one private L2 (a split-K weight gradient: one K slice per XCD instead of
+  // every slice fetched by 4-8 XCDs; performance only, any placement is correct).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, nb = gx * gy * (int)gridDim.z;
+    if (nb >= 16) {
+      const int lin = bx + gx * (by + gy * bz);
+      const int q = nb >> 3, r = nb & 7, xcd = lin & 7;
+      const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+      bx = logical % gx;
+      by = (logical / gx) % gy;
+      bz = logical / (gx * gy);
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const int nkb = num_kblocks<T, CH>(p.seg);
   // split-K: contiguous ranges of panels per z-slice
   const int per = (nkb + p.splitk - 1) / p.splitk;
-  const int it0 = blockIdx.z * per;
+  const int it0 = bz * per;
   const int it1 = min(nkb, it0 + per);
-  if (it0 >= it1 && blockIdx.z > 0) return;
+  if (it0 >= it1 && bz > 0) return;
 
   f32x4 acc[TM][TN];
   zero_acc(acc);
@@ -43,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const bool first = blockIdx.z == 0;
+  const bool first = bz == 0;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll

@@ -76,6 +76,8 @@ def test_two_ranks_one_gpu_match_single_process_global_batch():
     table = m.mu2_table.detach().cpu()
     for r in range(world):
         a, b = ret[r]["rows"]
-        torch.testing.assert_close(ret[r]["shard"], table[a:b], rtol=2e-4, atol=2e-5)
-        torch.testing.assert_close(ret[r]["w"], m.z2_pre_encoder.lstm.weight_hh_l1.detach().cpu(), rtol=2e-4, atol=2e-5)
-        torch.testing.assert_close(ret[r]["wd"], m.pre_decoder.lstm.weight_ih_l0.detach().cpu(), rtol=2e-4, atol=2e-5)
+        # 3 Adam steps of lr 1e-3 move a weight by <= 3e-3; Adam's g/sqrt(v) amplifies the f32 summation-order
+        # differences between the split and the global batch on near-zero gradients: allow 1e-4 absolute (3 % of a step)
+        torch.testing.assert_close(ret[r]["shard"], table[a:b], rtol=2e-4, atol=1e-4)
+        torch.testing.assert_close(ret[r]["w"], m.z2_pre_encoder.lstm.weight_hh_l1.detach().cpu(), rtol=2e-4, atol=1e-4)
+        torch.testing.assert_close(ret[r]["wd"], m.pre_decoder.lstm.weight_ih_l0.detach().cpu(), rtol=2e-4, atol=1e-4)
