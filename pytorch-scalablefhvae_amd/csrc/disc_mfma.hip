@@ -55,8 +55,10 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, i = lane & 15;
-  const int x0 = blockIdx.x * 256 + wave * 64;
-  const int y_begin = blockIdx.y * a.chunk;
+  // blockIdx.x = chunk of the STREAMED set: round-robin XCD placement then gives every XCD (private L2) 1/8 of the
+  // streamed vectors (the table, 128 MB at 1M rows) instead of all of them
+  const int x0 = blockIdx.y * 256 + wave * 64;
+  const int y_begin = blockIdx.x * a.chunk;
   const int y_end = min(a.NY, y_begin + a.chunk);
   const float gscale = MODE == 1 ? (*a.gsc) * a.gmul : 0.f;
 
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
         mm = nm;
       }
       const int x = x0 + t * 16 + i;
-      if (g == 0 && x < a.NX) a.part[(int64_t)blockIdx.y * a.NX + x] = make_float2(mm, ss);
+      if (g == 0 && x < a.NX) a.part[(int64_t)blockIdx.x * a.NX + x] = make_float2(mm, ss);
     }
   } else {
     // grad_x = 2c (G - X W); lane holds G[x = 16t+i][d = 16dj + 4g + reg]; transpose through LDS -> row-contiguous atomics
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
     __syncthreads();
     for (int e = tid; e < 256 * D; e += 256) {
       const int rr = e / D, d = e % D;
-      const int x = blockIdx.x * 256 + rr;
+      const int x = blockIdx.y * 256 + rr;
       if (x < a.NX) atomicAdd(a.G + (int64_t)x * D + d, tr[rr][d]);
     }
   }
@@ -310,7 +312,7 @@ int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_
   a.part = part;
   a.chunk = mfma_chunk(B, S);
   *nchunks = (int)fh_cdiv(S, a.chunk);
-  dim3 grid((unsigned)fh_cdiv(B, 256), (unsigned)*nchunks);
+  dim3 grid((unsigned)*nchunks, (unsigned)fh_cdiv(B, 256));
   if (D == 32)
     hipLaunchKernelGGL((disc_mfma_kernel<32, 0>), grid, dim3(256), 0, st, a);
   else
@@ -337,7 +339,7 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
     a.x_is_query = 1;
     a.G = dq;
     a.chunk = mfma_chunk(B, S);
-    dim3 grid((unsigned)fh_cdiv(B, 256), (unsigned)fh_cdiv(S, a.chunk));
+    dim3 grid((unsigned)fh_cdiv(S, a.chunk), (unsigned)fh_cdiv(B, 256));
     if (D == 32)
       hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
     else
@@ -353,7 +355,7 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
     a.x_is_query = 0;
     a.G = dtable;
     a.chunk = mfma_chunk(S, B);
-    dim3 grid((unsigned)fh_cdiv(S, 256), (unsigned)fh_cdiv(B, a.chunk));
+    dim3 grid((unsigned)fh_cdiv(B, a.chunk), (unsigned)fh_cdiv(S, 256));
     if (D == 32)
       hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
     else
