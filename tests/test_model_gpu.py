@@ -246,3 +246,43 @@ def test_edge_cases_single_segment_single_row_and_bad_index(hb):
         close(got[k], want[k], what="out%d" % k)
     with pytest.raises(IndexError):
         f(x.cuda(), torch.tensor([3, 0]), 3, 7)
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-3), ("bf16", 2e-2)])
+def test_training_trajectory_matches_cpu_oracle(hb, dt, tol):
+    """'At matched ELBO': 12 Adam steps of the HIP model (FusedAdam, gradient sinks, persistent table) and of the CPU
+    oracle from the same initial weights, data and draws -- the loss and the bound stay together step by step
+    (f32: 2e-3 relative; bf16 operands: 2e-2)."""
+    from fhvae import FHVAE
+    from hip_optim import FusedAdam
+    from train_model import loss_function
+
+    T, F, H, D, B, S, steps = 20, 80, 64, 16, 64, 50, 12
+    torch.manual_seed(21)
+    ref = R.FHVAERef(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T)
+    table0 = torch.randn(S, D)
+    m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T, num_seqs=S, reference_compat=False, compute_dtype=dt)
+    m.load_state_dict(dict(ref.state_dict(), mu2_table=table0.clone()))
+    m.cuda()
+    opt = FusedAdam(m.parameters(), lr=1e-3, betas=(0.95, 0.999))
+    table = table0.clone().requires_grad_(True)
+    ropt = torch.optim.Adam(list(ref.parameters()) + [table], lr=1e-3, betas=(0.95, 0.999))
+    g = torch.Generator().manual_seed(5)
+    got, want = [], []
+    for k in range(steps):
+        x = torch.randn(B, T, F, generator=g)
+        idx = torch.randint(0, S, (B,), generator=g)
+        ns = torch.randint(20, 200, (B,), generator=g)
+        e2, e1 = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+        loss_ref, lb_ref = R.train_step(ref, ropt, table, x, idx, ns, e2, e1, alpha=10.0, reference_compat=False)
+        opt.zero_grad()
+        out = m(x.cuda(), idx, S, ns, eps=(e2, e1))
+        loss = loss_function(out[0], out[1], 10.0)
+        loss.backward()
+        opt.step()
+        got.append((loss.item(), out[0].mean().item() / T))
+        want.append((loss_ref.item(), lb_ref.mean().item() / T))
+    for k, ((lg, eg), (lw, ew)) in enumerate(zip(got, want)):
+        assert abs(lg - lw) <= tol * abs(lw), ("loss", k, lg, lw)
+        assert abs(eg - ew) <= tol * abs(ew), ("elbo nats/frame", k, eg, ew)
+    assert want[-1][0] < want[0][0]  # it trains
