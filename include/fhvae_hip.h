@@ -98,6 +98,8 @@ typedef struct fhvae_lstm_desc {
   int64_t B, T, I, Ic, H;
   /* inputs and parameters are ALWAYS f32 (master copies) */
   const float* x;   /* (T,B,I) time-major */
+  const void* x_lp; /* BF16 mode, optional: the same x already in bf16 (e.g. from fhvae_to_time_major); then the
+                       forward does not cast x again (two encoders share one input) */
   const float* xc;  /* (B,Ic) */
   const float* w_ih[FHVAE_MAX_LAYERS]; /* [4H, I+Ic] (l=0) / [4H, H] */
   const float* w_hh[FHVAE_MAX_LAYERS]; /* [4H, H] */

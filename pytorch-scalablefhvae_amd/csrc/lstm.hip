@@ -354,7 +354,7 @@ static Ops<u16> ops_bf16(const fhvae_lstm_desc* d) {
   Ops<u16> o = {};
   LpLayout L = lp_layout(d);
   const u16* base = (const u16*)d->lp;
-  o.x = base + L.x;
+  o.x = d->x_lp ? (const u16*)d->x_lp : base + L.x;
   o.xc = base + L.xc;
   for (int l = 0; l < d->L; ++l) {
     o.w_ih[l] = base + L.w_ih[l];
@@ -372,7 +372,7 @@ static int cast_operands(const fhvae_lstm_desc* d, hipStream_t st) {
   auto add = [&](const float* s, u16* dst, u16* dst_t, int64_t R, int64_t C) {
     if (R * C > 0) cb.it[cb.n++] = CastItem{s, dst, dst_t, R, C};
   };
-  add(d->x, base + L.x, nullptr, d->T * d->B, d->I);
+  if (!d->x_lp) add(d->x, base + L.x, nullptr, d->T * d->B, d->I);
   add(d->xc, base + L.xc, nullptr, d->B, d->Ic);
   for (int l = 0; l < d->L; ++l) {
     const int64_t kin = l == 0 ? d->I + d->Ic : d->H;

@@ -92,7 +92,7 @@ class FHVAE(FHVAEBase):
         x, _, _ = self._prep_inputs(x, torch.zeros(x.shape[0], dtype=torch.int64), 1)
         T = x.shape[1]
         dt = hb.BF16 if self.compute_dtype == "bf16" else hb.F32
-        x_tm = hb.to_time_major(x)
+        x_tm = hb.to_time_major(x, with_bf16=dt == hb.BF16)
         _, hn2 = self.z2_pre_encoder(x_tm, None, T, dt)
         z2_mu, z2_logvar, _ = self.z2_gauss_layer(hn2, sample=False)
         _, hn1 = self.z1_pre_encoder(x_tm, z2_mu, T, dt)
@@ -110,7 +110,7 @@ class FHVAE(FHVAEBase):
         e2, e1 = self._draw(eps, B, x.device)
 
         dt = hb.BF16 if self.compute_dtype == "bf16" else hb.F32
-        x_tm = hb.to_time_major(x)  # (T,B,F): contiguous per-step tiles for the step-fused cells
+        x_tm = hb.to_time_major(x, with_bf16=dt == hb.BF16)  # (T,B,F): contiguous per-step tiles for the step-fused cells
         _, hn2 = self.z2_pre_encoder(x_tm, None, T, dt)
         z2_mu, z2_logvar, z2_sample = self.z2_gauss_layer(hn2, e2)
         _, hn1 = self.z1_pre_encoder(x_tm, z2_sample, T, dt)

@@ -30,7 +30,7 @@ class LstmDesc(C.Structure):
     _fields_ = [
         ("dtype", _i32), ("L", _i32),
         ("B", _i64), ("T", _i64), ("I", _i64), ("Ic", _i64), ("H", _i64),
-        ("x", _vp), ("xc", _vp),
+        ("x", _vp), ("x_lp", _vp), ("xc", _vp),
         ("w_ih", _vp * MAX_LAYERS), ("w_hh", _vp * MAX_LAYERS),
         ("b_ih", _vp * MAX_LAYERS), ("b_hh", _vp * MAX_LAYERS),
         ("hs", _vp), ("cs", _vp), ("gates", _vp), ("hn", _vp), ("hs_top_f32", _vp), ("pre", _vp), ("lp", _vp),
@@ -383,22 +383,30 @@ def gauss_head(h, w_mu, b_mu, w_lv, b_lv, eps):
     return mu, lv, (smp if eps is not None else None)
 
 
-def to_time_major(x: torch.Tensor) -> torch.Tensor:
-    """(B,T,F) -> (T,B,F) copy (input data: no gradient)."""
+def to_time_major(x: torch.Tensor, with_bf16: bool = False):
+    """(B,T,F) -> (T,B,F) copy (input data: no gradient).  with_bf16: also return the bf16 copy the bf16 LSTM nets
+    consume (one pass produces both, and both encoders share it)."""
     _need_gpu(x)
     lib = load_library()
     x = _f32c(x.detach())
     B, T, F_ = x.shape
     out = torch.empty(T, B, F_, device=x.device, dtype=torch.float32)
+    if with_bf16:
+        lp = torch.empty(T, B, F_, device=x.device, dtype=torch.bfloat16)
+        with _Timed("fhvae_to_time_major"):
+            _check(lib.fhvae_to_time_major(_p(x), _p(lp), _p(out), B, T, F_, BF16, _stream()), "fhvae_to_time_major")
+        out._fh_lp = lp  # rides along with the f32 tensor; hip_binding.lstm_seq picks it up
+        return out
     with _Timed("fhvae_to_time_major"):
         _check(lib.fhvae_to_time_major(_p(x), _p(out), None, B, T, F_, F32, _stream()), "fhvae_to_time_major")
     return out
 
 
-def _fill_lstm_desc(d, dtype, dims, x_tm, xc, params):
+def _fill_lstm_desc(d, dtype, dims, x_tm, xc, params, x_lp=None):
     L, B, T, I, Ic, H = dims
     d.dtype, d.L, d.B, d.T, d.I, d.Ic, d.H = dtype, L, B, T, I, Ic, H
     d.x, d.xc = _p(x_tm), _p(xc)
+    d.x_lp = _p(x_lp) if dtype == BF16 else None
     for l in range(L):
         d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_p(params[4 * l + k]) for k in range(4))
 
@@ -417,6 +425,7 @@ class _LstmSeq(torch.autograd.Function):
         ctx.sinks = [_sink(p) for p in params]
         params = [_f32c(p) for p in params]
         H = params[1].shape[1]
+        x_lp = getattr(x_tm, "_fh_lp", None) if x_tm is not None else None
         x_tm = _f32c(x_tm) if x_tm is not None else None
         xc = _f32c(xc) if xc is not None else None
         I = x_tm.shape[2] if x_tm is not None else 0
@@ -436,7 +445,7 @@ class _LstmSeq(torch.autograd.Function):
         hs_top = torch.empty(T, B, H, **f32) if bf else None
         d = LstmDesc()
         dims = (L, B, T, I, Ic, H)
-        _fill_lstm_desc(d, dtype, dims, x_tm, xc, params)
+        _fill_lstm_desc(d, dtype, dims, x_tm, xc, params, x_lp)
         lp = None
         if bf:
             lp = torch.empty(int(lib.fhvae_lstm_lp_bytes(C.byref(d))), device=dev, dtype=torch.uint8)
@@ -444,6 +453,7 @@ class _LstmSeq(torch.autograd.Function):
         with _Timed("fhvae_lstm_seq_fwd"):
             _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")
         ctx.dims, ctx.dtype = dims, dtype
+        ctx.x_lp = x_lp
         ctx.save_for_backward(x_tm, xc, hs, cs, gates, lp, *params)
         return (hs_top if bf else hs[L - 1]), hn
 
@@ -461,7 +471,7 @@ class _LstmSeq(torch.autograd.Function):
         d_hn = _f32c(d_hn) if d_hn is not None else None
         bd = LstmBwdDesc()
         d = bd.f
-        _fill_lstm_desc(d, ctx.dtype, ctx.dims, x_tm, xc, params)
+        _fill_lstm_desc(d, ctx.dtype, ctx.dims, x_tm, xc, params, ctx.x_lp)
         pre = torch.empty(1, **f32)  # not used by the backward, must be non-NULL
         d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.pre, d.lp = _p(hs), _p(cs), _p(gates), None, None, _p(pre), _p(lp)
         dgates = torch.empty(L, T, B, 4 * H, device=dev, dtype=hs.dtype)
