@@ -59,6 +59,7 @@ struct Op<u16> {  // bf16 bit patterns
 struct RowIdent {
   int X;  // number of valid rows
   __device__ __forceinline__ int64_t operator()(int r) const { return r < X ? (int64_t)r : -1; }
+  __device__ __forceinline__ bool all_valid(int r0, int n) const { return r0 + n <= X; }
 };
 
 // LDS bytes for one operand tile of R rows and CH chunks (max of the KC and KM images)
@@ -318,6 +319,122 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
     }
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS staging (LDS-DMA, global_load_lds_dwordx4) for INTERIOR KC/KC tiles: no staging registers, the
+// next panel lands in the other LDS buffer while this one is multiplied, one barrier per panel instead of two.
+// The LDS destination of a wave-instruction is linear (wave-uniform base + lane*16 = 64/CH whole rows), so the XOR
+// swizzle is applied to the per-lane SOURCE chunk (guide rule 21): LDS position `pos` of row r receives global chunk
+// pos ^ (r & SW), the same involution the fragment reads use.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int R, int CH, class RowMap>
+__device__ __forceinline__ void glds_tile(char* lds_buf, const void* base_, int64_t ld, int x0, int k0, const RowMap& rm,
+                                          int rmod, int tid) {
+  constexpr int EPC = Op<T>::EPC;
+  constexpr int RPI = 64 / CH;        // rows written by one wave-instruction
+  constexpr int NI = R / (4 * RPI);   // instructions per wave
+  constexpr int SW = CH >= 16 ? 15 : CH - 1;
+  static_assert(R % (4 * RPI) == 0, "glds tile shape");
+  const int lane = tid & 63, wave = tid >> 6;
+  const T* base = (const T*)base_;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = (wave * NI + j) * RPI + lane / CH;
+    const int c = (lane % CH) ^ (row & SW);
+    uint32_t g32 = (uint32_t)rm(x0 + row);  // interior tile: every row valid
+    if (rmod > 0) g32 %= (uint32_t)rmod;
+    const T* src = base + (int64_t)g32 * ld + k0 + c * EPC;
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)(lds_buf + (wave * NI + j) * 1024), 16, 0, 0);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ bool seg_glds_ok(const Seg& s, int BK) {
+  constexpr int EPC = Op<T>::EPC;
+  return s.K == 0 || (s.a_kc && s.b_kc && (s.K % BK) == 0 && (s.lda % EPC) == 0 && (s.ldb % EPC) == 0 &&
+                      ((((uintptr_t)s.A) | ((uintptr_t)s.B)) & 15) == 0);
+}
+
+// NBUF = 2: the next panel lands in the other buffer under this panel's MFMAs (one barrier per panel; few, large
+// workgroups).  NBUF = 1: one buffer, two barriers per panel, half the LDS: more workgroups per CU hide the latency
+// instead (large batches).
+template <typename T, int BM, int BN, int WM, int WN, int CH, int NBUF = 2>
+struct GldsTile {
+  static constexpr int A_BYTES = BM * CH * 16, B_BYTES = BN * CH * 16;
+  static constexpr int SMEM = NBUF * (A_BYTES + B_BYTES);
+};
+
+// whole contraction (no split-K) of an interior KC/KC tile
+template <typename T, int BM, int BN, int WM, int WN, int CH, int NBUF, class ARowMap, class BRowMap>
+__device__ __forceinline__ void mainloop_glds(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const Seg (&segs)[2], int m0, int n0,
+                                              const ARowMap& arm, const BRowMap& brm, char* smem) {
+  using GT = GldsTile<T, BM, BN, WM, WN, CH, NBUF>;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int BK = CH * Op<T>::EPC;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 15, q = lane >> 4;
+  const int nkb0 = segs[0].K / BK, nkb = nkb0 + segs[1].K / BK;
+  auto issue = [&](int p) {
+    const int si = p < nkb0 ? 0 : 1;
+    const int k0 = (p < nkb0 ? p : p - nkb0) * BK;
+    const Seg& s = segs[si];
+    char* buf = smem + (NBUF == 2 ? (p & 1) : 0) * (GT::A_BYTES + GT::B_BYTES);
+    glds_tile<T, BM, CH>(buf, s.A, s.lda, m0, k0, arm, s.a_rmod, tid);
+    glds_tile<T, BN, CH>(buf + GT::A_BYTES, s.B, s.ldb, n0, k0, brm, 0, tid);
+  };
+  if (nkb > 0) issue(0);
+  for (int p = 0; p < nkb; ++p) {
+    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier: panel p has landed, and every
+                      // wave is done with the buffer panel p+1 is about to overwrite
+    if (NBUF == 2 && p + 1 < nkb) issue(p + 1);
+    const char* As = smem + (NBUF == 2 ? (p & 1) : 0) * (GT::A_BYTES + GT::B_BYTES);
+    const char* Bs = As + GT::A_BYTES;
+#pragma unroll 2
+    for (int j = 0; j < CH / 4; ++j) {
+      if constexpr (sizeof(T) == 4) {
+        float a[TM][4], b[TN][4];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const uint4 u = *(const uint4*)(As + kc_off<CH>(wm * (TM * 16) + tm * 16 + r, (j << 2) | q));
+          a[tm][0] = __uint_as_float(u.x), a[tm][1] = __uint_as_float(u.y), a[tm][2] = __uint_as_float(u.z), a[tm][3] = __uint_as_float(u.w);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const uint4 u = *(const uint4*)(Bs + kc_off<CH>(wn * (TN * 16) + tn * 16 + r, (j << 2) | q));
+          b[tn][0] = __uint_as_float(u.x), b[tn][1] = __uint_as_float(u.y), b[tn][2] = __uint_as_float(u.z), b[tn][3] = __uint_as_float(u.w);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+      } else {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          a[tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<CH>(wm * (TM * 16) + tm * 16 + r, (j << 2) | q)));
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          b[tn] = __builtin_bit_cast(bf16x8, *(const uint4*)(Bs + kc_off<CH>(wn * (TN * 16) + tn * 16 + r, (j << 2) | q)));
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+    }
+    if (NBUF == 1 && p + 1 < nkb) {
+      __syncthreads();  // every wave has read the single buffer
+      issue(p + 1);
+    }
+  }
+  __syncthreads();  // the epilogue may reuse LDS / the kernel may fall through to another phase
 }
 
 template <int TM, int TN>

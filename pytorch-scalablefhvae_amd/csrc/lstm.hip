@@ -15,6 +15,7 @@
 // pre-activations never touch HBM.
 #include "gemm_launch.h"
 #include "trace.h"
+#include <cstdlib>
 
 namespace fh {
 
@@ -41,6 +42,7 @@ struct FwdJob {
 template <typename T>
 struct FwdJobs {
   int B, H;
+  int glds;  // use the LDS-DMA main loop where the tile allows it
   FwdJob<T> job[FHVAE_MAX_LAYERS];
 };
 
@@ -52,6 +54,7 @@ struct GateRowMap {
     int gate = (n & 63) >> 4;
     return unit < H ? (int64_t)gate * H + unit : -1;
   }
+  __device__ __forceinline__ bool all_valid(int n0, int n) const { return ((n0 + n) >> 6) * 16 <= H; }
 };
 
 template <typename T>
@@ -86,7 +89,9 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
   constexpr int TM = TL::TM;
   static_assert(TL::TN == 4, "one wave = one 64-column gate group");
   constexpr bool kPrefetch = TM == 1;
-  __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
+  constexpr int NBUF = CH >= 32 ? 2 : 1;  // wide panels = few large workgroups: double buffer; narrow: occupancy
+  using GT = GldsTile<T, BM, BN, WM, WN, CH, NBUF>;
+  __shared__ __attribute__((aligned(16))) char smem[TL::SMEM > GT::SMEM ? TL::SMEM : GT::SMEM];
   const FwdJob<T>& J = jobs.job[blockIdx.z];
   const int B = jobs.B, H = jobs.H;
   // blockIdx.x walks the ROW tiles: workgroups are dealt round-robin over the 8 XCDs by linear id, so every XCD
@@ -120,7 +125,13 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
     }
   }
   const int nkb = num_kblocks<T, CH>(J.seg);
-  mainloop<T, BM, BN, WM, WN, CH, true, true>(acc, J.seg, m0, B, n0, (int)gridDim.y * BN, arm, brm, 0, nkb, smem);
+  // interior tiles with panel-aligned K take the LDS-DMA path; edges / odd shapes the register-staged one
+  const bool dma = jobs.glds && m0 + BM <= B && brm.all_valid(n0, BN) && seg_glds_ok<T>(J.seg[0], TL::BK) &&
+                   seg_glds_ok<T>(J.seg[1], TL::BK);
+  if (dma)
+    mainloop_glds<T, BM, BN, WM, WN, CH, NBUF>(acc, J.seg, m0, n0, arm, brm, smem);
+  else
+    mainloop<T, BM, BN, WM, WN, CH, true, true>(acc, J.seg, m0, B, n0, (int)gridDim.y * BN, arm, brm, 0, nkb, smem);
 
   if (!uok) return;
 #pragma unroll
@@ -177,6 +188,7 @@ struct BwdJob {
 template <typename T>
 struct BwdJobs {
   int B, H;
+  int glds;
   BwdJob<T> job[FHVAE_MAX_LAYERS];
 };
 
@@ -185,7 +197,9 @@ template <typename T, int BM, int BN, int WM, int WN, int CH>
 __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs) {
   using TL = Tile<T, BM, BN, WM, WN, CH>;
   constexpr int TM = TL::TM, TN = TL::TN;
-  __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
+  constexpr int NBUF = CH >= 32 ? 2 : 1;
+  using GT = GldsTile<T, BM, BN, WM, WN, CH, NBUF>;
+  __shared__ __attribute__((aligned(16))) char smem[(sizeof(T) == 2 && GT::SMEM > TL::SMEM) ? GT::SMEM : TL::SMEM];
   const BwdJob<T>& J = jobs.job[blockIdx.z];
   const int B = jobs.B, H = jobs.H;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // row tiles on x: XCD-local activations (see the forward cell)
@@ -195,8 +209,15 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int nkb = num_kblocks<T, CH>(J.seg);
-  // f32: W is the untransposed master weight (KM operand); bf16: the transposed bf16 copy (KC operand)
-  mainloop<T, BM, BN, WM, WN, CH, true, sizeof(T) == 2>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
+  // f32: W is the untransposed master weight (KM operand); bf16: the transposed bf16 copy (KC operand) -> LDS-DMA path
+  bool dma = false;
+  if constexpr (sizeof(T) == 2)
+    dma = jobs.glds && m0 + BM <= B && n0 + BN <= H && seg_glds_ok<T>(J.seg[0], TL::BK) && seg_glds_ok<T>(J.seg[1], TL::BK);
+  if (dma) {
+    if constexpr (sizeof(T) == 2) mainloop_glds<T, BM, BN, WM, WN, CH, NBUF>(acc, J.seg, m0, n0, arm, brm, smem);
+  } else {
+    mainloop<T, BM, BN, WM, WN, CH, true, sizeof(T) == 2>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
+  }
 
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -412,6 +433,7 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     FwdJobs<T> jobs = {};
     jobs.B = (int)B;
     jobs.H = (int)H;
+    jobs.glds = getenv("FHVAE_NO_GLDS") ? 0 : 1;
     int nj = 0;
     for (int l = 0; l < L; ++l) {
       const int64_t t = w - l;
@@ -480,6 +502,7 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     BwdJobs<T> jobs = {};
     jobs.B = (int)B;
     jobs.H = (int)H;
+    jobs.glds = getenv("FHVAE_NO_GLDS") ? 0 : 1;
     int nj = 0;
     for (int l = L - 1; l >= 0; --l) {
       const int64_t u = w - (L - 1 - l);
