@@ -23,11 +23,17 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, int row, int col
   if (p.Clp) p.Clp[(int64_t)row * p.ldclp + col] = f2bf(v);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC>
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool DMA = false>
 __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   using TL = Tile<T, BM, BN, WM, WN, CH>;
   constexpr int TM = TL::TM, TN = TL::TN;
-  __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
+  // LDS-DMA main loop for interior KC/KC tiles without split-K.  A separate instantiation (it needs 128 KB of LDS for
+  // its two buffers): launched only for small grids, where one workgroup per CU is all there is and the latency of a
+  // panel is the whole cost (256x1024x512 bf16: 8.1 -> 7.0 us); larger grids prefer 2+ workgroups per CU.
+  constexpr bool kDma = DMA && AKC && BKC;
+  constexpr int NBUF = CH >= 32 ? 2 : 1;
+  using GT = GldsTile<T, BM, BN, WM, WN, CH, NBUF>;
+  __shared__ __attribute__((aligned(16))) char smem[(kDma && GT::SMEM > TL::SMEM) ? GT::SMEM : TL::SMEM];
   // XCD-aware tile order (guide T1, bijective form): workgroups are dealt round-robin over the 8 XCDs by linear id;
   // remap so that each XCD owns a CONTIGUOUS range of logical tiles (x fastest, then y, then the K slice): tiles that
   // share an operand panel then share one private L2 (a split-K weight gradient: one K slice per XCD instead of
@@ -55,7 +61,14 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   f32x4 acc[TM][TN];
   zero_acc(acc);
   RowIdent arm{p.M}, brm{p.N};
-  mainloop<T, BM, BN, WM, WN, CH, AKC, BKC>(acc, p.seg, m0, p.M, n0, p.N, arm, brm, it0, it1, smem);
+  bool dma = false;
+  if constexpr (kDma)
+    dma = p.splitk == 1 && m0 + BM <= p.M && n0 + BN <= p.N && seg_glds_ok<T>(p.seg[0], TL::BK) && seg_glds_ok<T>(p.seg[1], TL::BK);
+  if (dma) {
+    if constexpr (kDma) mainloop_glds<T, BM, BN, WM, WN, CH, NBUF>(acc, p.seg, m0, n0, arm, brm, smem);
+  } else {
+    mainloop<T, BM, BN, WM, WN, CH, AKC, BKC>(acc, p.seg, m0, p.M, n0, p.N, arm, brm, it0, it1, smem);
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -110,8 +123,12 @@ template <typename T, int BM, int BN, int CH>
 static void launch_fast(const GemmParams& p, dim3 grid, hipStream_t st) {
   const int akc = p.seg[0].K > 0 ? p.seg[0].a_kc : p.seg[1].a_kc;
   const int bkc = p.seg[0].K > 0 ? p.seg[0].b_kc : p.seg[1].b_kc;
-  if (akc && bkc)
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, true, true>), grid, dim3(kThreads), 0, st, p);
+  if (akc && bkc) {
+    if (CH == 32 && BM == 64 && p.splitk == 1 && (int64_t)grid.x * grid.y <= 256)
+      hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, true, true, CH == 32 && BM == 64>), grid, dim3(kThreads), 0, st, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, true, true>), grid, dim3(kThreads), 0, st, p);
+  }
   else if (!akc && !bkc)
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, false, false>), grid, dim3(kThreads), 0, st, p);
   else if constexpr (sizeof(T) == 4) {
