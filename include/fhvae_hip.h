@@ -37,6 +37,9 @@ enum {
 };
 
 #define FHVAE_MAX_LAYERS 4
+/* BF16 mode: the first bytes of fhvae_lstm_desc.lp are the sync block of the persistent (cluster) recurrence kernels;
+   u32 word 0 = status of the last such launch on that workspace: 0 ok, non-zero = the launch gave up (outputs invalid). */
+#define FHVAE_LSTM_SYNC_BYTES 16384
 
 int fhvae_abi_version(void);
 /* human-readable text for a return code (static storage) */

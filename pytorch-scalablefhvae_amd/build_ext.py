@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libfhvae_hip.so")
-SOURCES = ["gemm.hip", "lstm.hip", "loss.hip", "disc_mfma.hip", "data.hip", "trace.hip"]
+SOURCES = ["gemm.hip", "lstm.hip", "lstm_cluster.hip", "loss.hip", "disc_mfma.hip", "data.hip", "trace.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
 
 

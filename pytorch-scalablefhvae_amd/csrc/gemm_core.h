@@ -328,7 +328,8 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
 // swizzle is applied to the per-lane SOURCE chunk (guide rule 21): LDS position `pos` of row r receives global chunk
 // pos ^ (r & SW), the same involution the fragment reads use.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int R, int CH, class RowMap>
+// AUX: cache-policy bits of the load (16 = sc1: served by L2, bypasses this CU's vector L1).
+template <typename T, int R, int CH, int AUX = 0, class RowMap>
 __device__ __forceinline__ void glds_tile(char* lds_buf, const void* base_, int64_t ld, int x0, int k0, const RowMap& rm,
                                           int rmod, int tid) {
   constexpr int EPC = Op<T>::EPC;
@@ -346,7 +347,7 @@ __device__ __forceinline__ void glds_tile(char* lds_buf, const void* base_, int6
     if (rmod > 0) g32 %= (uint32_t)rmod;
     const T* src = base + (int64_t)g32 * ld + k0 + c * EPC;
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                     (void __attribute__((address_space(3)))*)(lds_buf + (wave * NI + j) * 1024), 16, 0, 0);
+                                     (void __attribute__((address_space(3)))*)(lds_buf + (wave * NI + j) * 1024), 16, 0, AUX);
   }
 }
 

@@ -14,6 +14,7 @@
 // same (segment, unit)) and applies sigmoid/tanh + the cell update in registers: the (B,4H)
 // pre-activations never touch HBM.
 #include "gemm_launch.h"
+#include "lstm_cluster.h"
 #include "trace.h"
 #include <cstdlib>
 
@@ -267,10 +268,13 @@ struct CastItem {
   int64_t R, C;
 };
 struct CastBatch {
+  unsigned* sync;  // the workspace's sync block (lstm_cluster.h): cleared here, once per forward
   int n;
   CastItem it[4 * FHVAE_MAX_LAYERS + 2];
 };
 __global__ void cast_batch_kernel(CastBatch cb) {
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < kSyncWordsUsed; i += blockDim.x) cb.sync[i] = 0u;
   const CastItem& c = cb.it[blockIdx.y];
   const int64_t n = c.R * c.C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -327,7 +331,7 @@ struct LpLayout {
 };
 static LpLayout lp_layout(const fhvae_lstm_desc* d) {
   LpLayout o;
-  int64_t n = 0;
+  int64_t n = FHVAE_LSTM_SYNC_BYTES / 2;  // the cluster kernels' sync block comes first (lstm_cluster.h)
   auto take = [&](int64_t cnt) {
     int64_t at = n;
     n += (cnt + 7) / 8 * 8;
@@ -390,6 +394,7 @@ static int cast_operands(const fhvae_lstm_desc* d, hipStream_t st) {
   LpLayout L = lp_layout(d);
   u16* base = (u16*)d->lp;
   CastBatch cb = {};
+  cb.sync = (unsigned*)d->lp;
   auto add = [&](const float* s, u16* dst, u16* dst_t, int64_t R, int64_t C) {
     if (R * C > 0) cb.it[cb.n++] = CastItem{s, dst, dst_t, R, C};
   };
@@ -425,6 +430,13 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     p.splitk = 1;
     int e = launch_gemm(p, d->dtype, st);
     if (e) return e;
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (cluster_eligible(d)) {  // persistent form: the whole recurrence in one launch (lstm_cluster.hip)
+      ClusterWeights cw = {};
+      for (int l = 0; l < L; ++l) cw.w_ih[l] = op.w_ih[l], cw.w_hh[l] = op.w_hh[l], cw.w_ih_t[l] = op.w_ih_t[l], cw.w_hh_t[l] = op.w_hh_t[l];
+      return cluster_fwd(d, cw, st);
+    }
   }
   const int64_t pre_tstride = I > 0 ? B * 4 * H : 0;
   T* hs = (T*)d->hs;
@@ -496,6 +508,13 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
   const int64_t B = d->B, T_ = d->T, Ic = d->Ic, H = d->H;
   const int L = d->L;
   constexpr bool kF32 = sizeof(T) == 4;
+  if constexpr (!kF32) {
+    if (cluster_eligible(d)) {  // the forward on this workspace took the persistent form too (same predicate)
+      ClusterWeights cw = {};
+      for (int l = 0; l < L; ++l) cw.w_ih[l] = op.w_ih[l], cw.w_hh[l] = op.w_hh[l], cw.w_ih_t[l] = op.w_ih_t[l], cw.w_hh_t[l] = op.w_hh_t[l];
+      return cluster_bwd(bd, cw, st);
+    }
+  }
   T* dg = (T*)bd->dgates;
   // f32: the weights are read untransposed as KM operands; bf16: the transposed copies [H,4H] are KC operands.
   for (int64_t w = 0; w < T_ + L - 1; ++w) {

@@ -1,0 +1,32 @@
+// lstm_cluster.h -- persistent "cluster" form of the bf16 LSTM recurrence (lstm_cluster.hip), used by lstm.hip.
+#pragma once
+#include "common.h"
+
+namespace fh {
+
+// The first FHVAE_LSTM_SYNC_BYTES of the bf16 workspace (fhvae_lstm_desc.lp) are the kernels' sync block (u32 words):
+constexpr int kSyncStatus = 0;    // 0 = ok; bit 0: a bounded spin gave up, bit 1: an XCD received more than 32 workgroups
+constexpr int kSyncXcdCnt = 16;   // 8 arrival counters (one per XCD): a workgroup's slot on its XCD
+constexpr int kSyncFlags = 64;    // + cluster * 32: one word per workgroup of the cluster = the last step it has published
+constexpr int kSyncWordsUsed = kSyncFlags + 64 * 32;
+// The block is zeroed once per forward (by the operand-cast launch that precedes every bf16 forward); the launches that
+// then share it -- forward chunks, later the backward's -- are numbered 0, 1, ... (`seq`, a constant of the call, so it
+// survives graph replay): launch `seq` owns the tickets [32 seq, 32 seq + 32) of every XCD counter and the flag epochs
+// (seq * kSeqEpochs, (seq + 1) * kSeqEpochs].
+constexpr int kSeqEpochs = 4096;
+
+struct ClusterWeights {  // bf16 operand copies in the workspace
+  const u16* w_ih[FHVAE_MAX_LAYERS];    // [4H, H]   (l >= 1)
+  const u16* w_hh[FHVAE_MAX_LAYERS];    // [4H, H]
+  const u16* w_ih_t[FHVAE_MAX_LAYERS];  // [H, 4H]   (l >= 1)
+  const u16* w_hh_t[FHVAE_MAX_LAYERS];  // [H, 4H]
+};
+
+// whether this device / shape can run the cluster kernels (gfx950 with 256 CUs, bf16, H in {128, 256}, L <= 2, ...)
+bool cluster_eligible(const fhvae_lstm_desc* d);
+// the recurrence of fhvae_lstm_seq_fwd after the layer-0 input projection (d->pre filled): all T steps, all layers
+int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st);
+// the recurrence of fhvae_lstm_seq_bwd: fills dgates (and dgsum when Ic > 0)
+int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st);
+
+}  // namespace fh

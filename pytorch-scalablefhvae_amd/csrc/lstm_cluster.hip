@@ -1,0 +1,775 @@
+// lstm_cluster.hip -- K1 in its persistent form: the whole bf16 recurrence of a net (all T steps, all layers) in ONE
+// launch of 256 workgroups, one per CU.
+//
+// Why: one launch per wavefront step costs a dependent kernel boundary plus a cold start of every tile (27 us per
+// step at B = 2048, 11 us at B = 256).  The recurrence only couples the HIDDEN UNITS of one batch row, so the batch is
+// cut into CLUSTERS of NU = H/16 workgroups that never talk to another cluster; a cluster is formed from workgroups
+// of ONE XCD (HW_REG_XCC_ID), so everything its members exchange stays in that XCD's L2:
+//   * workgroup `me` of a cluster owns hidden units [16 me, 16 me + 16) of EVERY layer: its 64 gate columns of W_hh[l]
+//     (and W_ih[l], l >= 1) live in LDS for the whole launch (H = 256, L = 2: 96 KB), the cell state c of its
+//     (row, unit) pairs lives in registers;
+//   * per wavefront step s (layer l at time s - l) the only shared data is h^l_{s-l-1} (bf16, written once, at a fresh
+//     address: hs is the saved-for-backward buffer anyway); it is BOTH the recurrent operand of layer l and the input
+//     of layer l+1, so it is staged once (LDS-DMA, 16-KB panels, double buffered) and multiplied into both
+//     accumulators;
+//   * hand-off per step: plain stores -> s_waitcnt vmcnt(0) (the write-through L1 has delivered them to the XCD's L2)
+//     -> workgroup barrier -> one agent-scope flag store; consumers poll the NU flags of their cluster with L1-bypassing
+//     loads, then read h with sc1 loads.  No agent-scope fence: an L2 write-back / invalidate costs 17+ us per step
+//     (tools/exp/xcd_barrier.hip: 1.1-1.4 us per step for this form, 17-27 us with fences) and is not needed inside
+//     one XCD.  The same-XCD premise is not assumed from blockIdx: a workgroup reads its XCD from the hardware
+//     register and takes a slot by an atomic ticket on that XCD's counter; if an XCD ever received more than 32
+//     workgroups the launch aborts (status word, NaN outputs), it never computes from a stale line.
+//   * every spin is bounded and watches the abort word: a lost workgroup ends the launch, it cannot hang the GPU.
+//
+// Semantics are those of lstm.hip's step kernels (same accumulation order per k is NOT promised: parity is the bf16
+// tolerance of the model tests).  f32 (parity mode) stays on the per-step kernels.
+#include "lstm_cluster.h"
+
+#include <cstdlib>
+#include <cstring>
+
+#include "gemm_core.h"
+#include "trace.h"
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+namespace fh {
+
+constexpr unsigned kSpinLimit = 1u << 21;  // polls of >= one L2 round trip each: gives up after about a second
+constexpr int kGrid = 256;                  // one workgroup per CU, 32 per XCD
+constexpr int kSc1 = 16;                    // aux bits of an L1-bypassing load
+
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
+}
+
+// slot of this workgroup on its XCD: x * 32 + slot, or -1 (abort)
+__device__ __forceinline__ int cluster_join(unsigned* sync, int seq, int* s_word) {
+  if (threadIdx.x == 0) {
+    const unsigned x = xcc_id();
+    int v = -1;
+    if (x < 8) {
+      const unsigned slot = __hip_atomic_fetch_add(sync + kSyncXcdCnt + x, 1u, RLX_AGENT) - 32u * (unsigned)seq;
+      if (slot < 32) v = (int)(x * 32 + slot);
+    }
+    if (v < 0) __hip_atomic_fetch_or(sync + kSyncStatus, 2u, RLX_AGENT);
+    s_word[0] = v;
+  }
+  __syncthreads();
+  return s_word[0];
+}
+
+// every member of the cluster has published `epoch`; false = abort.  EVERY wave polls for itself (one 64-byte line per
+// poll): the waves stage and multiply their own rows, so nothing has to re-converge here.
+__device__ __forceinline__ bool cluster_wait(unsigned* sync, const unsigned* flags, int nu, unsigned epoch) {
+  const int lane = threadIdx.x & 63;
+  for (unsigned spins = 0;; ++spins) {
+    unsigned v = epoch, st = 0;
+    if (lane < nu) v = __hip_atomic_load(flags + lane, RLX_AGENT);
+    if (lane == 63) st = __hip_atomic_load(sync + kSyncStatus, RLX_AGENT);
+    if (__any(st != 0)) return false;
+    if (__all(v >= epoch)) break;
+    if (spins > kSpinLimit) {
+      if (lane == 0) __hip_atomic_fetch_or(sync + kSyncStatus, 1u, RLX_AGENT);
+      return false;
+    }
+  }
+  asm volatile("" ::: "memory");
+  return true;
+}
+
+// all stores of this workgroup have reached the XCD's L2, then ONE lane raises the flag
+__device__ __forceinline__ void cluster_publish(unsigned* flags, int me, unsigned epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flags + me, epoch, RLX_AGENT);
+}
+
+// row r of the cluster -> physical batch row, clamped to the launch's last row (loads only; stores are masked)
+struct ClRowMap {
+  int r0, rlast;
+  __device__ __forceinline__ int64_t operator()(int r) const {
+    const int x = r0 + r;
+    return x < rlast ? x : rlast;
+  }
+};
+// virtual gate column n (0..63: gate-major, 16 units) of this workgroup -> physical weight row
+struct ClGateMap {
+  int H, u0;
+  __device__ __forceinline__ int64_t operator()(int n) const { return (int64_t)(n >> 4) * H + u0 + (n & 15); }
+};
+struct ClUnitMap {
+  int u0;
+  __device__ __forceinline__ int64_t operator()(int n) const { return u0 + n; }
+};
+
+// Wave-private operand staging.  A wave multiplies only its own TM*16 batch rows, so it stages them itself (LDS-DMA,
+// L1-bypassing) into its own ring of kRing 4-KB panels and orders itself with s_waitcnt vmcnt(n) alone: no workgroup
+// barrier inside the contraction, kRing-1 panels (12 KB per wave, 48 KB per CU) in flight under the MFMAs.
+constexpr int kRing = 4;
+constexpr int kPanel = 4096;
+
+// one panel = ROWS rows x CH chunks (ROWS * CH * 16 = 4096): rows row_base.. of the source, contraction offset k0
+template <int ROWS, int CH, class RowMap>
+__device__ __forceinline__ void glds_wave_panel(char* lds, const u16* base, int64_t ld, int k0, const RowMap& rm, int row_base,
+                                                int lane) {
+  constexpr int RPI = 64 / CH;  // rows per wave-instruction
+  constexpr int SW = CH >= 16 ? 15 : CH - 1;
+  static_assert(ROWS * CH * 16 == kPanel && ROWS % RPI == 0, "panel shape");
+#pragma unroll
+  for (int j = 0; j < ROWS / RPI; ++j) {
+    const int row = j * RPI + lane / CH;
+    const int c = (lane % CH) ^ (row & SW);
+    const u16* src = base + (int64_t)(uint32_t)rm(row_base + row) * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)(lds + j * 1024), 16, 0, kSc1);
+  }
+}
+// wait until at most `younger` panels (4 DMA instructions each) issued after the needed one are still in flight
+__device__ __forceinline__ void wait_panels(int younger) {
+  if (younger >= 2)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (younger == 1)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// phase clock (100 MHz) of one workgroup into the log, when asked for
+#define CL_TLOG(slot)                                                                                      \
+  do {                                                                                                     \
+    if (tl && tid == 0) tl[(slot)] = wall_clock64();                                                        \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+struct ClFwd {
+  int B, T, NU, Mc;    // B: row count of the (T,B,.) buffers; NU workgroups per cluster; Mc rows per cluster
+  int row0, nrows;     // rows handled by this launch
+  int seq;             // number of this launch on the workspace's sync block (lstm_cluster.h)
+  const u16* w_ih[2];  // [4H,H] bf16 (l = 1)
+  const u16* w_hh[2];
+  const float* b_ih[2];
+  const float* b_hh[2];
+  const float* pre;  // layer-0 input projection incl. biases: (T,B,4H), or (B,4H) with pre_tstride = 0
+  int64_t pre_tstride;
+  u16* hs;     // (L,T,B,H)
+  float* cs;   // (L,T,B,H)
+  u16* gates;  // (L,T,B,4H)
+  float* hs_top_f32;  // optional (T,B,H)
+  float* hn;          // optional (B, L*H)
+  unsigned* sync;
+  unsigned long long* tlog;  // optional phase clock log of cluster 0 / member 0 (tools/prof_cluster.py)
+};
+
+template <int H, int L, int RB>
+struct ClFwdCfg {
+  static constexpr int HC = H / 8;                        // 16-byte chunks per h row
+  static constexpr int TM = RB >= 64 ? RB / 64 : 1;       // 16-row tiles per wave
+  static constexpr int WR = TM * 16;                      // rows of one wave
+  static constexpr int PCH = kPanel / (WR * 16);          // chunks per row in a 4-KB panel (TM = 2: 8, TM = 1: 16)
+  static constexpr int NPP = HC / PCH;                    // panels per source
+  static constexpr int W_BYTES = 64 * HC * 16;
+  static constexpr int NW = 2 * L - 1;
+  static constexpr int SMEM = NW * W_BYTES + 4 * kRing * kPanel;
+  static_assert(PCH >= 8 && HC % PCH == 0, "panel shape");
+};
+
+template <int H, int L, int RB>
+__global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
+  using CF = ClFwdCfg<H, L, RB>;
+  constexpr int HC = CF::HC, TM = CF::TM, PCH = CF::PCH, NPP = CF::NPP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* ring = smem + CF::NW * CF::W_BYTES + wave * (kRing * kPanel);  // this wave's staging ring
+  const int r = lane & 15, q = lane >> 4;
+
+  const int info = cluster_join(p.sync, p.seq, (int*)(smem + CF::NW * CF::W_BYTES));  // (the rings are idle until step 1)
+  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
+  if (info < 0) return;
+  const int NU = p.NU;
+  const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
+  const int r0 = p.row0 + cluster * p.Mc;
+  const int rend = min(p.row0 + p.nrows, r0 + p.Mc);
+  if (r0 >= rend) return;  // the whole cluster leaves: nobody waits for it
+  unsigned* flags = p.sync + kSyncFlags + cluster * 32;
+  const int u0 = me * 16;
+  const int B = p.B, T = p.T;
+
+  // ---- weights of this workgroup's 64 gate columns -> LDS, once
+  {
+    ClGateMap gm{H, u0};
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      glds_tile<u16, 64, HC>(Wl + (2 * l) * CF::W_BYTES, p.w_hh[l], H, 0, 0, gm, 0, tid);
+      if (l > 0) glds_tile<u16, 64, HC>(Wl + (2 * l - 1) * CF::W_BYTES, p.w_ih[l], H, 0, 0, gm, 0, tid);
+    }
+  }
+  // MFMA roles: the WEIGHT fragment is the first operand, the h fragment the second, so the 16x16 result has the
+  // hidden unit on (lane>>4)*4 + reg and the batch row on lane&15: a lane owns i,f,g,o of FOUR CONSECUTIVE units of one
+  // row -> every f32 output leaves as one 16-byte store, every bf16 output as one 8-byte store
+  const int uq = u0 + q * 4;  // first of this lane's 4 units
+  f32x4 bias[L][4];
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bias[l][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (l > 0) bias[l][g] = *(const f32x4*)(p.b_ih[l] + g * H + uq) + *(const f32x4*)(p.b_hh[l] + g * H + uq);
+    }
+
+  const int wrow0 = wave * (TM * 16);       // first cluster row of this wave
+  const bool wact = wrow0 < RB;             // waves beyond the tile only help staging
+  f32x4 creg[L][TM];
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) creg[l][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ClRowMap arm{r0, rend - 1};
+  auto pack4 = [](const f32x4& v) -> uint2 {
+    return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+  };
+
+  unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
+  const int nsteps = T + L - 1;
+  for (int s = 0; s < nsteps; ++s) {
+    CL_TLOG(s * 8 + 0);
+    // (1) layer 0's additive term for t = s: independent of the exchange, fetched under the wait
+    f32x4 padd[TM][4];
+    if (s < T && wact) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = r0 + wrow0 + tm * 16 + r;
+        const float* pp = p.pre + (int64_t)s * p.pre_tstride + (int64_t)(row < rend ? row : rend - 1) * (4 * H) + uq;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) padd[tm][g] = *(const f32x4*)(pp + g * H);
+      }
+    }
+    // (2) h of step s-1 from every member
+    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
+
+    CL_TLOG(s * 8 + 1);
+    // (3) contraction: sources l with tau = s-l-1 in [0,T): h^l_tau feeds layer l (recurrent) and layer l+1 (input)
+    f32x4 acc[L][TM][4];
+#pragma unroll
+    for (int l = 0; l < L; ++l) zero_acc(acc[l]);
+    const int lo = s - T > 0 ? s - T : 0;
+    const int hi = s - 1 < L - 1 ? s - 1 : L - 1;
+    const int npan = hi >= lo ? (hi - lo + 1) * NPP : 0;
+    auto issue = [&](int n) {
+      const int l = lo + n / NPP, pp = n % NPP;
+      const u16* src = p.hs + ((int64_t)(l * T + (s - l - 1)) * B) * H;
+      glds_wave_panel<CF::WR, PCH>(ring + (n % kRing) * kPanel, src, H, pp * PCH * 8, arm, wrow0, lane);
+    };
+    if (wact) {
+      for (int n = 0; n < kRing - 1 && n < npan; ++n) issue(n);
+      for (int n = 0; n < npan; ++n) {
+        wait_panels(npan - 1 - n < kRing - 2 ? npan - 1 - n : kRing - 2);  // panel n has landed
+        if (n + kRing - 1 < npan) issue(n + kRing - 1);  // into the slot consumed one iteration ago
+        const int l = lo + n / NPP, pp = n % NPP;
+        const char* As = ring + (n % kRing) * kPanel;
+#pragma unroll
+        for (int ll = 0; ll < L; ++ll) {
+          if (ll != l) continue;
+          const bool rec = s - ll < T;  // layer ll itself is active at this step
+          const char* Whh = Wl + (2 * ll) * CF::W_BYTES;
+          const char* Wih = Wl + (2 * ll + 1) * CF::W_BYTES;  // of layer ll+1 (exists when ll+1 < L)
+#pragma unroll 2
+          for (int j = 0; j < PCH / 4; ++j) {
+            bf16x8 a[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+              a[tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<PCH>(tm * 16 + r, (j << 2) | q)));
+            const int kc = pp * PCH + ((j << 2) | q);
+            if (rec) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Whh + kc_off<HC>(g * 16 + r, kc)));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                  acc[ll][tm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[ll][tm][g], 0, 0, 0);
+              }
+            }
+            if (ll + 1 < L) {
+              constexpr int kTop = L - 1;
+              const int lu = ll + 1 < L ? ll + 1 : kTop;  // (constant after unrolling; the guard keeps the index in range)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Wih + kc_off<HC>(g * 16 + r, kc)));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                  acc[lu][tm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[lu][tm][g], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+
+    CL_TLOG(s * 8 + 2);
+    // (4) gates + cell update for the active layers; h leaves first (it is what the other members wait for)
+    uint2 gpk[L][TM][4];  // activated gates, packed bf16
+    f32x4 hreg[L][TM];
+    if (wact) {
+#pragma unroll
+      for (int ll = 0; ll < L; ++ll) {
+        const int t = s - ll;
+        if (t < 0 || t >= T) continue;
+        const int64_t lt = (int64_t)ll * T + t;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int row = r0 + wrow0 + tm * 16 + r;
+          f32x4 gv[4], c, h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gv[g] = acc[ll][tm][g] + (ll == 0 ? padd[tm][g] : bias[ll][g]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float ig = sigmoidf_(gv[0][i]), fg = sigmoidf_(gv[1][i]), gg = tanhf_(gv[2][i]), og = sigmoidf_(gv[3][i]);
+            c[i] = fg * creg[ll][tm][i] + ig * gg;
+            h[i] = og * tanhf_(c[i]);
+            gv[0][i] = ig, gv[1][i] = fg, gv[2][i] = gg, gv[3][i] = og;
+          }
+          creg[ll][tm] = c;
+          hreg[ll][tm] = h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gpk[ll][tm][g] = pack4(gv[g]);
+          if (row < rend) *(uint2*)(p.hs + (lt * B + row) * H + uq) = pack4(h);
+        }
+      }
+    }
+    CL_TLOG(s * 8 + 3);
+    // (5) publish step s (also the barrier that frees the staging buffers for the next step)
+    if (s + 1 < nsteps) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));
+    CL_TLOG(s * 8 + 4);
+    // (6) everything only the backward / the caller reads: off the critical path, under the next step's wait
+    if (wact) {
+#pragma unroll
+      for (int ll = 0; ll < L; ++ll) {
+        const int t = s - ll;
+        if (t < 0 || t >= T) continue;
+        const int64_t lt = (int64_t)ll * T + t;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int row = r0 + wrow0 + tm * 16 + r;
+          if (row >= rend) continue;
+          *(f32x4*)(p.cs + (lt * B + row) * H + uq) = creg[ll][tm];
+          u16* go = p.gates + (lt * B + row) * (4 * H) + uq;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = gpk[ll][tm][g];
+          if (ll == L - 1 && p.hs_top_f32) *(f32x4*)(p.hs_top_f32 + ((int64_t)t * B + row) * H + uq) = hreg[ll][tm];
+          if (p.hn && t == T - 1) *(f32x4*)(p.hn + (int64_t)row * (L * H) + ll * H + uq) = hreg[ll][tm];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: dh^l_t = dg^l_{t+1} . W_hh[l] + dg^{l+1}_t . W_ih[l+1] (+ external), elementwise LSTM backward -> dg^l_t.
+// Same decomposition: member `me` owns hidden units [16 me, 16 me + 16) of every layer; its 16 rows of W_hh[l]^T and of
+// W_ih[l+1]^T (K = 4H) live in LDS; dc and the running sum of dg live in registers.  What the members exchange per step
+// is dg^l of the previous step (bf16, fresh address per (l,t)): the matrix dg^l_{tau} is at once the recurrent operand
+// of layer l (time tau-1) and the from-above operand of layer l-1 (time tau), so it is staged once.
+// ---------------------------------------------------------------------------------------------
+struct ClBwd {
+  int B, T, NU, Mc;
+  int row0, nrows;
+  int seq;
+  const u16* w_ih_t[2];  // [H,4H] bf16 (l = 1)
+  const u16* w_hh_t[2];  // [H,4H]
+  const u16* gates;      // (L,T,B,4H) saved activations
+  const float* cs;       // (L,T,B,H)
+  const float* d_hs_top; // (T,B,H) or NULL
+  const float* d_hn;     // (B,L*H) or NULL
+  u16* dg;               // (L,T,B,4H) out
+  float* dgsum;          // (B,4H) out: sum over t of layer 0's dg, or NULL
+  unsigned* sync;
+  unsigned long long* tlog;
+};
+
+template <int H, int L, int RB>
+struct ClBwdCfg {
+  static constexpr int GC = 4 * H / 8;                    // 16-byte chunks per dg row
+  static constexpr int TM = RB >= 64 ? RB / 64 : 1;
+  static constexpr int WR = TM * 16;
+  static constexpr int PCH = kPanel / (WR * 16);
+  static constexpr int NPP = GC / PCH;
+  static constexpr int KB = GC / 64;                      // weight slices are kept as KB blocks of [16 rows][64 chunks]
+  static constexpr int W_BYTES = 16 * GC * 16;
+  static constexpr int NW = 2 * L - 1;
+  static constexpr int SMEM = NW * W_BYTES + 4 * kRing * kPanel;
+  static_assert(GC % 64 == 0 && GC % PCH == 0 && PCH >= 8, "panel shape");
+};
+
+__device__ __forceinline__ f32x4 unpack4(uint2 v) {
+  return f32x4{bf2f((u16)(v.x & 0xffff)), bf2f((u16)(v.x >> 16)), bf2f((u16)(v.y & 0xffff)), bf2f((u16)(v.y >> 16))};
+}
+
+template <int H, int L, int RB>
+__global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
+  using CF = ClBwdCfg<H, L, RB>;
+  constexpr int TM = CF::TM, PCH = CF::PCH, NPP = CF::NPP, KB = CF::KB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* ring = smem + CF::NW * CF::W_BYTES + wave * (kRing * kPanel);  // this wave's staging ring
+  const int r = lane & 15, q = lane >> 4;
+
+  const int info = cluster_join(p.sync, p.seq, (int*)(smem + CF::NW * CF::W_BYTES));  // (the rings are idle until step 1)
+  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
+  if (info < 0) return;
+  const int NU = p.NU;
+  const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
+  const int r0 = p.row0 + cluster * p.Mc;
+  const int rend = min(p.row0 + p.nrows, r0 + p.Mc);
+  if (r0 >= rend) return;
+  unsigned* flags = p.sync + kSyncFlags + cluster * 32;
+  const int u0 = me * 16, uq = u0 + q * 4;
+  const int B = p.B, T = p.T;
+  constexpr int G = 4 * H;
+
+  // ---- this member's 16 rows of every transposed weight -> LDS, once: slot 2l = W_hh[l]^T, slot 2l-1 = W_ih[l]^T
+  {
+    ClUnitMap um{u0};
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        glds_tile<u16, 16, 64>(Wl + (2 * l) * CF::W_BYTES + kb * 16384, p.w_hh_t[l], G, 0, kb * 512, um, 0, tid);
+        if (l > 0) glds_tile<u16, 16, 64>(Wl + (2 * l - 1) * CF::W_BYTES + kb * 16384, p.w_ih_t[l], G, 0, kb * 512, um, 0, tid);
+      }
+  }
+  const int wrow0 = wave * (TM * 16);
+  const bool wact = wrow0 < RB;
+  f32x4 dcreg[L][TM], ccur[L][TM], dgs[TM][4];
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) dcreg[l][tm] = ccur[l][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dgs[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ClRowMap arm{r0, rend - 1};
+  auto pack4 = [](const f32x4& v) -> uint2 {
+    return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+  };
+  unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
+
+  const int nsteps = T + L - 1;
+  for (int s = 0; s < nsteps; ++s) {
+    CL_TLOG(s * 8 + 0);
+    // (1) the saved activations / cell states / external gradients of this step's (layer, time) pairs: independent
+    //     of the exchange, fetched under the wait.  Layer l handles t = T-1 - (s - (L-1-l)).
+    uint2 gk[L][TM][4];
+    f32x4 cprev[L][TM], ext[L][TM];
+    if (wact) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const int t = T - 1 - (s - (L - 1 - l));
+        if (t < 0 || t >= T) continue;
+        const int64_t lt = (int64_t)l * T + t;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int row0_ = r0 + wrow0 + tm * 16 + r;
+          const int64_t row = row0_ < rend ? row0_ : rend - 1;
+          const u16* gp = p.gates + (lt * B + row) * G + uq;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gk[l][tm][g] = *(const uint2*)(gp + g * H);
+          if (t == T - 1) ccur[l][tm] = *(const f32x4*)(p.cs + (lt * B + row) * H + uq);
+          cprev[l][tm] = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + row) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (l == L - 1 && p.d_hs_top) e = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + row) * H + uq);
+          if (t == T - 1 && p.d_hn) e += *(const f32x4*)(p.d_hn + row * (L * H) + l * H + uq);
+          ext[l][tm] = e;
+        }
+      }
+    }
+    // (2) dg of step s-1 from every member
+    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
+    CL_TLOG(s * 8 + 1);
+
+    // (3) contraction.  Source l = dg^l at tau_l = T - s + (L-1-l), valid for 0 <= tau_l <= T-1 (s >= 1).
+    f32x4 acc[L][TM];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc[l][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // tau_l <= T-1  <=>  l >= L - s;   tau_l >= 0  <=>  l <= T - s + L - 1: a contiguous range of layers
+    const int lo = L - s > 0 ? L - s : 0;
+    const int hi = T - s + L - 1 < L - 1 ? T - s + L - 1 : L - 1;
+    const int npan = hi >= lo ? (hi - lo + 1) * NPP : 0;
+    auto issue = [&](int n) {
+      const int l = lo + n / NPP, pp = n % NPP;
+      const int tau = T - s + (L - 1 - l);
+      const u16* src = p.dg + ((int64_t)(l * T + tau) * B) * G;
+      glds_wave_panel<CF::WR, PCH>(ring + (n % kRing) * kPanel, src, G, pp * PCH * 8, arm, wrow0, lane);
+    };
+    if (wact) {
+      for (int n = 0; n < kRing - 1 && n < npan; ++n) issue(n);
+      for (int n = 0; n < npan; ++n) {
+        wait_panels(npan - 1 - n < kRing - 2 ? npan - 1 - n : kRing - 2);
+        if (n + kRing - 1 < npan) issue(n + kRing - 1);
+        const int l = lo + n / NPP, pp = n % NPP;
+        const char* As = ring + (n % kRing) * kPanel;
+#pragma unroll
+        for (int ll = 0; ll < L; ++ll) {
+          if (ll != l) continue;
+          const bool rec = T - s + (L - 1 - ll) - 1 >= 0;  // layer ll itself is active (t = tau - 1 >= 0)
+          const char* Whh = Wl + (2 * ll) * CF::W_BYTES;
+          const char* Wih = Wl + (ll > 0 ? 2 * ll - 1 : 0) * CF::W_BYTES;  // W_ih[ll]^T: consumed by layer ll-1
+#pragma unroll
+          for (int j = 0; j < PCH / 4; ++j) {
+            bf16x8 a[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+              a[tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<PCH>(tm * 16 + r, (j << 2) | q)));
+            const int kc = pp * PCH + ((j << 2) | q);
+            const int woff = (kc >> 6) * 16384 + kc_off<64>(r, kc & 63);
+            if (rec) {
+              const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Whh + woff));
+#pragma unroll
+              for (int tm = 0; tm < TM; ++tm) acc[ll][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[ll][tm], 0, 0, 0);
+            }
+            if (ll > 0) {
+              const int ld = ll > 0 ? ll - 1 : 0;
+              const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Wih + woff));
+#pragma unroll
+              for (int tm = 0; tm < TM; ++tm) acc[ld][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[ld][tm], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    CL_TLOG(s * 8 + 2);
+
+    // (4) elementwise LSTM backward -> dg^l_t (what the other members wait for)
+    if (wact) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const int t = T - 1 - (s - (L - 1 - l));
+        if (t < 0 || t >= T) continue;
+        const int64_t lt = (int64_t)l * T + t;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int row = r0 + wrow0 + tm * 16 + r;
+          const f32x4 ig = unpack4(gk[l][tm][0]), fg = unpack4(gk[l][tm][1]), gg = unpack4(gk[l][tm][2]), og = unpack4(gk[l][tm][3]);
+          const f32x4 dh = acc[l][tm] + ext[l][tm];
+          f32x4 dp[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float tc = tanhf_(ccur[l][tm][i]);
+            float dc = dh[i] * og[i] * (1.f - tc * tc);
+            if (t != T - 1) dc += dcreg[l][tm][i];
+            const float d_o = dh[i] * tc;
+            const float d_i = dc * gg[i], d_f = dc * cprev[l][tm][i], d_g = dc * ig[i];
+            dcreg[l][tm][i] = dc * fg[i];
+            dp[0][i] = d_i * ig[i] * (1.f - ig[i]);
+            dp[1][i] = d_f * fg[i] * (1.f - fg[i]);
+            dp[2][i] = d_g * (1.f - gg[i] * gg[i]);
+            dp[3][i] = d_o * og[i] * (1.f - og[i]);
+          }
+          ccur[l][tm] = cprev[l][tm];  // c_{t-1} is the next step's c_t
+          if (l == 0 && p.dgsum) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgs[tm][g] += dp[g];
+          }
+          if (row < rend) {
+            u16* go = p.dg + (lt * B + row) * G + uq;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = pack4(dp[g]);
+          }
+        }
+      }
+    }
+    CL_TLOG(s * 8 + 3);
+    // (5) publish
+    if (s + 1 < nsteps) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));
+    CL_TLOG(s * 8 + 4);
+  }
+  if (p.dgsum && wact) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = r0 + wrow0 + tm * 16 + r;
+      if (row >= rend) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(f32x4*)(p.dgsum + (int64_t)row * G + g * H + uq) = dgs[tm][g];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static bool device_ok() {
+  static int ok = -1;
+  if (ok < 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    ok = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess)
+      ok = (strncmp(pr.gcnArchName, "gfx950", 6) == 0 && pr.multiProcessorCount == kGrid) ? 1 : 0;
+  }
+  return ok == 1;
+}
+
+bool cluster_eligible(const fhvae_lstm_desc* d) {
+  if (getenv("FHVAE_NO_CLUSTER")) return false;
+  if (d->dtype != FHVAE_BF16 || !d->lp) return false;
+  if (d->H != 256 && d->H != 128) return false;
+  if (d->L > 2 || d->T + d->L >= kSeqEpochs) return false;
+  return device_ok();
+}
+
+template <int H, int L, int RB>
+static int launch_fwd_rb(const ClFwd& p, hipStream_t st) {
+  using CF = ClFwdCfg<H, L, RB>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_kernel<H, L, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, L, RB>), dim3(kGrid), dim3(kThreads), CF::SMEM, st, p);
+  return fh_launch_status();
+}
+
+template <int H, int L>
+static int launch_fwd(const ClFwd& p, int RB, hipStream_t st) {
+  switch (RB) {
+    case 16: return launch_fwd_rb<H, L, 16>(p, st);
+    case 32: return launch_fwd_rb<H, L, 32>(p, st);
+    case 64: return launch_fwd_rb<H, L, 64>(p, st);
+    default: return launch_fwd_rb<H, L, 128>(p, st);
+  }
+}
+
+// rows per cluster and the tile that holds them
+static void cluster_rows(int64_t nrows, int NC, int* Mc, int* RB) {
+  int64_t m = (nrows + NC - 1) / NC;
+  m = (m + 15) / 16 * 16;
+  *Mc = (int)m;
+  *RB = m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : 128;
+}
+
+int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st) {
+  const int H = (int)d->H, L = d->L;
+  const int NU = H / 16, NC = kGrid / NU;
+  const int64_t chunk = (int64_t)NC * 128;
+  for (int64_t row0 = 0; row0 < d->B; row0 += chunk) {
+    const int64_t nrows = d->B - row0 < chunk ? d->B - row0 : chunk;
+    ClFwd p = {};
+    int RB;
+    cluster_rows(nrows, NC, &p.Mc, &RB);
+    p.B = (int)d->B;
+    p.T = (int)d->T;
+    p.NU = NU;
+    p.row0 = (int)row0;
+    p.nrows = (int)nrows;
+    for (int l = 0; l < L; ++l) {
+      p.w_ih[l] = w.w_ih[l];
+      p.w_hh[l] = w.w_hh[l];
+      p.b_ih[l] = d->b_ih[l];
+      p.b_hh[l] = d->b_hh[l];
+    }
+    p.pre = d->pre;
+    p.pre_tstride = d->I > 0 ? d->B * 4 * d->H : 0;
+    p.hs = (u16*)d->hs;
+    p.cs = d->cs;
+    p.gates = (u16*)d->gates;
+    p.hs_top_f32 = d->hs_top_f32;
+    p.hn = d->hn;
+    p.sync = (unsigned*)d->lp;
+    p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES / 2) : nullptr;
+    p.seq = (int)(row0 / chunk);
+    double fl = 0;
+    for (int l = 0; l < L; ++l) fl += 2.0 * nrows * 4 * H * ((l > 0 ? d->T * H : 0) + (d->T - 1) * (double)H);
+    const int ts = trace_begin(st, kTraceFwdCell, fl);
+    int e;
+    if (H == 256)
+      e = L == 1 ? launch_fwd<256, 1>(p, RB, st) : launch_fwd<256, 2>(p, RB, st);
+    else
+      e = L == 1 ? launch_fwd<128, 1>(p, RB, st) : launch_fwd<128, 2>(p, RB, st);
+    trace_end(st, ts);
+    if (e) return e;
+  }
+  return FHVAE_OK;
+}
+
+// the backward re-arms the sync block itself (a plain kernel: memset nodes misbehaved under graph replay), so it does
+// not depend on which form the forward took or on how often the backward runs
+__global__ void cluster_sync_zero_kernel(unsigned* sync) {
+  for (int i = threadIdx.x; i < kSyncWordsUsed; i += blockDim.x) sync[i] = 0u;
+}
+
+template <int H, int L, int RB>
+static int launch_bwd_rb(const ClBwd& p, hipStream_t st) {
+  using CF = ClBwdCfg<H, L, RB>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_cluster_kernel<H, L, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((lstm_bwd_cluster_kernel<H, L, RB>), dim3(kGrid), dim3(kThreads), CF::SMEM, st, p);
+  return fh_launch_status();
+}
+
+template <int H, int L>
+static int launch_bwd(const ClBwd& p, int RB, hipStream_t st) {
+  switch (RB) {
+    case 16: return launch_bwd_rb<H, L, 16>(p, st);
+    case 32: return launch_bwd_rb<H, L, 32>(p, st);
+    case 64: return launch_bwd_rb<H, L, 64>(p, st);
+    default: return launch_bwd_rb<H, L, 128>(p, st);
+  }
+}
+
+int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
+  const fhvae_lstm_desc* d = &bd->f;
+  const int H = (int)d->H, L = d->L;
+  const int NU = H / 16, NC = kGrid / NU;
+  const int64_t chunk = (int64_t)NC * 128;
+  hipLaunchKernelGGL(cluster_sync_zero_kernel, dim3(1), dim3(256), 0, st, (unsigned*)d->lp);
+  for (int64_t row0 = 0; row0 < d->B; row0 += chunk) {
+    const int64_t nrows = d->B - row0 < chunk ? d->B - row0 : chunk;
+    ClBwd p = {};
+    int RB;
+    cluster_rows(nrows, NC, &p.Mc, &RB);
+    p.B = (int)d->B;
+    p.T = (int)d->T;
+    p.NU = NU;
+    p.row0 = (int)row0;
+    p.nrows = (int)nrows;
+    p.seq = (int)(row0 / chunk);
+    for (int l = 0; l < L; ++l) {
+      p.w_ih_t[l] = w.w_ih_t[l];
+      p.w_hh_t[l] = w.w_hh_t[l];
+    }
+    p.gates = (const u16*)d->gates;
+    p.cs = d->cs;
+    p.d_hs_top = bd->d_hs_top;
+    p.d_hn = bd->d_hn;
+    p.dg = (u16*)bd->dgates;
+    p.dgsum = d->Ic > 0 ? bd->dgsum : nullptr;
+    p.sync = (unsigned*)d->lp;
+    p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES / 2) : nullptr;
+    double fl = 0;
+    for (int l = 0; l < L; ++l) fl += 2.0 * nrows * H * ((l < L - 1 ? d->T * 4.0 * H : 0) + (d->T - 1) * 4.0 * H);
+    const int ts = trace_begin(st, kTraceBwdCell, fl);
+    int e;
+    if (H == 256)
+      e = L == 1 ? launch_bwd<256, 1>(p, RB, st) : launch_bwd<256, 2>(p, RB, st);
+    else
+      e = L == 1 ? launch_bwd<128, 1>(p, RB, st) : launch_bwd<128, 2>(p, RB, st);
+    trace_end(st, ts);
+    if (e) return e;
+  }
+  return FHVAE_OK;
+}
+
+}  // namespace fh

@@ -411,6 +411,20 @@ def _fill_lstm_desc(d, dtype, dims, x_tm, xc, params, x_lp=None):
         d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_p(params[4 * l + k]) for k in range(4))
 
 
+# the most recent bf16 workspaces (fhvae_lstm_desc.lp): word 0 of each is the status of the persistent recurrence
+# kernels that last ran on it (include/fhvae_hip.h, FHVAE_LSTM_SYNC_BYTES)
+LSTM_WORKSPACES: list = []
+
+
+def lstm_sync_status() -> int:
+    """OR of the status words of the recent bf16 LSTM workspaces (synchronises).  Non-zero: a persistent recurrence
+    launch gave up (bounded spin expired / unexpected workgroup placement) and its outputs are invalid."""
+    st = 0
+    for lp in LSTM_WORKSPACES:
+        st |= int(lp[:4].view(torch.int32).item())
+    return st
+
+
 class _LstmSeq(torch.autograd.Function):
     """Multi-layer LSTM over the whole segment (K1).  Inputs: x_tm (T,B,I) or None, xc (B,Ic) or None,
     then per layer w_ih, w_hh, b_ih, b_hh (all f32).  Outputs: hs_top (T,B,H) f32 and hn (B, L*H).
@@ -449,6 +463,8 @@ class _LstmSeq(torch.autograd.Function):
         lp = None
         if bf:
             lp = torch.empty(int(lib.fhvae_lstm_lp_bytes(C.byref(d))), device=dev, dtype=torch.uint8)
+            LSTM_WORKSPACES.append(lp)
+            del LSTM_WORKSPACES[:-16]
         d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.pre, d.lp = _p(hs), _p(cs), _p(gates), _p(hn), _p(hs_top), _p(pre), _p(lp)
         with _Timed("fhvae_lstm_seq_fwd"):
             _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")

@@ -1,0 +1,78 @@
+"""The persistent (cluster) form of the bf16 LSTM recurrence (csrc/lstm_cluster.hip) against the per-step kernels
+(csrc/lstm.hip) on the same inputs: same arithmetic (bf16 MFMA operands, f32 accumulate and cell state), different
+schedule, so the two agree to a few bf16 ulps; and against torch.nn.LSTM at the bf16 tolerance of test_ops_gpu."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hb():
+    import build_ext
+
+    build_ext.build(verbose=False)
+    import hip_binding
+
+    hip_binding.load_library()
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return hip_binding
+
+
+def _run(hb, x_tm, xc, T, params, g_out, g_hn, cluster):
+    if cluster:
+        os.environ.pop("FHVAE_NO_CLUSTER", None)
+    else:
+        os.environ["FHVAE_NO_CLUSTER"] = "1"
+    try:
+        ps = [p.detach().clone().requires_grad_(True) for p in params]
+        xcd = xc.detach().clone().requires_grad_(True) if xc is not None else None
+        hs_top, hn = hb.lstm_seq(x_tm, xcd, T, ps, hb.BF16)
+        ((hs_top * g_out).sum() + (hn * g_hn).sum()).backward()
+        torch.cuda.synchronize()
+        return hs_top.detach(), hn.detach(), [p.grad for p in ps], (xcd.grad if xcd is not None else None)
+    finally:
+        os.environ.pop("FHVAE_NO_CLUSTER", None)
+
+
+# (B, T, I, Ic, H, L): whole tiles, ragged clusters, a batch smaller than the cluster count, one layer, H = 128,
+# more rows than one launch covers (B > 16 clusters x 128 rows), T = 1
+CASES = [(256, 20, 80, 0, 256, 2), (100, 7, 80, 32, 256, 2), (16, 5, 0, 64, 256, 2), (5, 3, 80, 0, 256, 2),
+         (2048, 20, 80, 0, 256, 2), (300, 6, 40, 0, 128, 2), (64, 4, 80, 0, 256, 1), (2500, 3, 80, 32, 256, 2),
+         (700, 1, 80, 0, 256, 2), (1000, 9, 0, 64, 128, 1)]
+
+
+@pytest.mark.parametrize("B,T,I,Ic,H,L", CASES)
+def test_cluster_matches_step_kernels(hb, B, T, I, Ic, H, L):
+    torch.manual_seed(B + 7 * T + H)
+    lstm = torch.nn.LSTM(I + Ic, H, L, batch_first=True)
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    params = [getattr(lstm, n).detach().cuda() for n in names]
+    x = torch.randn(B, T, I) if I else None
+    xc = torch.randn(B, Ic) if Ic else None
+    x_tm = x.transpose(0, 1).contiguous().cuda() if I else None
+    xcd = xc.cuda() if Ic else None
+    g_out, g_hn = torch.randn(T, B, H).cuda(), torch.randn(B, L * H).cuda()
+    a = _run(hb, x_tm, xcd, T, params, g_out, g_hn, cluster=True)
+    assert hb.lstm_sync_status() == 0, "a persistent recurrence launch gave up"
+    b = _run(hb, x_tm, xcd, T, params, g_out, g_hn, cluster=False)
+    # forward: |h| <= 1; bf16 ulp at 1 is 7.8e-3
+    for what, u, v in (("hs_top", a[0], b[0]), ("hn", a[1], b[1])):
+        d = (u - v).abs()
+        assert torch.isfinite(u).all(), what
+        assert d.max().item() < 2e-2 and d.mean().item() < 5e-4, (what, d.max().item(), d.mean().item())
+    for n, gu, gv in zip(names, a[2], b[2]):
+        scale = gv.abs().max().item() + 1e-30
+        assert (gu - gv).abs().max().item() < 2e-2 * scale, (n, (gu - gv).abs().max().item(), scale)
+    if Ic:
+        scale = b[3].abs().max().item() + 1e-30
+        assert (a[3] - b[3]).abs().max().item() < 2e-2 * scale
+    # against torch.nn.LSTM (f32, CPU)
+    parts = ([x] if I else []) + ([xc[:, None, :].expand(B, T, Ic)] if Ic else [])
+    out, (hn, _) = lstm(torch.cat(parts, -1))
+    ref = out.transpose(0, 1)
+    assert (a[0].cpu() - ref).abs().max().item() < 3e-2 * ref.abs().max().item()
+    hn_cat = torch.cat([hn[l] for l in range(L)], -1)
+    assert (a[1].cpu() - hn_cat).abs().max().item() < 3e-2 * hn_cat.abs().max().item()
