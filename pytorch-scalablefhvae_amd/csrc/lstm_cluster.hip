@@ -603,6 +603,320 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// SMALL batches (at most 32 rows per cluster, B <= 512): the step is pure latency, so the four waves split the
+// CONTRACTION instead of the rows.  Wave w = (row tile w / KSP, k-part w % KSP) loads its k-steps of the exchanged
+// operand straight into registers (L1-bypassing buffer loads: a lane's 16 bytes are its MFMA fragment), multiplies
+// them against the stationary weights, the partial tiles are summed through LDS and wave (rt, l) finishes layer l.
+// One L2 round trip for the operand, a quarter of the MFMA / LDS work per wave.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, int64_t byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, kSc1);
+  return uint4{v.x, v.y, v.z, v.w};
+}
+
+template <int H, int L, int RB>
+__global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
+  constexpr int HC = H / 8, KS = H / 32;
+  constexpr int KSP = 64 / RB;    // waves per row tile
+  constexpr int KPW = KS / KSP;   // k32-steps of each source per wave
+  constexpr int W_BYTES = 64 * HC * 16;
+  constexpr int NW = 2 * L - 1;
+  static_assert(KSP >= L && KS % KSP == 0, "k split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;
+  char* Part = smem + NW * W_BYTES;             // [wave][L][4] tiles of 1 KB
+  int* s_word = (int*)(Part + 4 * L * 4 * 1024);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int rt = wave / KSP, kp = wave % KSP;
+
+  const int info = cluster_join(p.sync, p.seq, s_word);
+  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
+  if (info < 0) return;
+  const int NU = p.NU;
+  const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
+  const int r0 = p.row0 + cluster * p.Mc;
+  const int rend = min(p.row0 + p.nrows, r0 + p.Mc);
+  if (r0 >= rend) return;
+  unsigned* flags = p.sync + kSyncFlags + cluster * 32;
+  const int u0 = me * 16, uq = u0 + q * 4;
+  const int B = p.B, T = p.T;
+  {
+    ClGateMap gm{H, u0};
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      glds_tile<u16, 64, HC>(Wl + (2 * l) * W_BYTES, p.w_hh[l], H, 0, 0, gm, 0, tid);
+      if (l > 0) glds_tile<u16, 64, HC>(Wl + (2 * l - 1) * W_BYTES, p.w_ih[l], H, 0, 0, gm, 0, tid);
+    }
+  }
+  const int row = r0 + rt * 16 + r;
+  const int64_t rowc = row < rend ? row : rend - 1;
+  const bool epi = kp < L;  // this wave finishes layer kp of its row tile
+  f32x4 bias[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bias[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (epi && kp > 0) bias[g] = *(const f32x4*)(p.b_ih[kp] + g * H + uq) + *(const f32x4*)(p.b_hh[kp] + g * H + uq);
+  }
+  f32x4 creg = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto pack4 = [](const f32x4& v) -> uint2 {
+    return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+  };
+  const __amdgpu_buffer_rsrc_t hs_rs = make_rsrc(p.hs);
+  unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
+  __syncthreads();  // weights have landed
+
+  const int nsteps = T + L - 1;
+  for (int s = 0; s < nsteps; ++s) {
+    CL_TLOG(s * 8 + 0);
+    f32x4 padd[4];
+    if (kp == 0 && s < T) {
+      const float* pp = p.pre + (int64_t)s * p.pre_tstride + rowc * (4 * H) + uq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) padd[g] = *(const f32x4*)(pp + g * H);
+    }
+    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
+    CL_TLOG(s * 8 + 1);
+
+    uint4 a[L][KPW];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int tau = s - l - 1;
+      if (tau < 0 || tau >= T) continue;
+      const int64_t base = ((((int64_t)l * T + tau) * B + rowc) * H + (kp * KPW * 4 + q) * 8) * 2;
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) a[l][j] = load_sc1(hs_rs, base + j * 64);
+    }
+    f32x4 acc[L][4];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[l][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int tau = s - l - 1;
+      if (tau < 0 || tau >= T) continue;
+      const bool rec = s - l < T;
+      const char* Whh = Wl + (2 * l) * W_BYTES;
+      const char* Wih = Wl + (2 * l + 1) * W_BYTES;
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a[l][j]);
+        const int kc = ((kp * KPW + j) << 2) | q;
+        if (rec) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            acc[l][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(Whh + kc_off<HC>(g * 16 + r, kc))), av,
+                                                                acc[l][g], 0, 0, 0);
+        }
+        if (l + 1 < L) {
+          constexpr int kTop = L - 1;
+          const int lu = l + 1 < L ? l + 1 : kTop;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            acc[lu][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(Wih + kc_off<HC>(g * 16 + r, kc))), av,
+                                                                 acc[lu][g], 0, 0, 0);
+        }
+      }
+    }
+    // partial tiles -> LDS, then wave (rt, l) sums the KSP parts of layer l
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(f32x4*)(Part + ((wave * L + l) * 4 + g) * 1024 + lane * 16) = acc[l][g];
+    __syncthreads();
+    CL_TLOG(s * 8 + 2);
+    const int t = s - kp;
+    const bool act = epi && t >= 0 && t < T;
+    uint2 gpk[4];
+    f32x4 hreg;
+    if (act) {
+      f32x4 gv[4], c;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        gv[g] = kp == 0 ? padd[g] : bias[g];
+#pragma unroll
+        for (int k = 0; k < KSP; ++k) gv[g] += *(const f32x4*)(Part + (((rt * KSP + k) * L + kp) * 4 + g) * 1024 + lane * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ig = sigmoidf_(gv[0][i]), fg = sigmoidf_(gv[1][i]), gg = tanhf_(gv[2][i]), og = sigmoidf_(gv[3][i]);
+        c[i] = fg * creg[i] + ig * gg;
+        hreg[i] = og * tanhf_(c[i]);
+        gv[0][i] = ig, gv[1][i] = fg, gv[2][i] = gg, gv[3][i] = og;
+      }
+      creg = c;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gpk[g] = pack4(gv[g]);
+      if (row < rend) *(uint2*)(p.hs + (((int64_t)kp * T + t) * B + row) * H + uq) = pack4(hreg);
+    }
+    CL_TLOG(s * 8 + 3);
+    if (s + 1 < nsteps) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));  // (its barrier also frees Part)
+    CL_TLOG(s * 8 + 4);
+    if (act && row < rend) {
+      const int64_t lt = (int64_t)kp * T + t;
+      *(f32x4*)(p.cs + (lt * B + row) * H + uq) = creg;
+      u16* go = p.gates + (lt * B + row) * (4 * H) + uq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = gpk[g];
+      if (kp == L - 1 && p.hs_top_f32) *(f32x4*)(p.hs_top_f32 + ((int64_t)t * B + row) * H + uq) = hreg;
+      if (p.hn && t == T - 1) *(f32x4*)(p.hn + (int64_t)row * (L * H) + kp * H + uq) = hreg;
+    }
+  }
+}
+
+template <int H, int L, int RB>
+__global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
+  constexpr int G = 4 * H, GC = G / 8, KB = GC / 64, KS = G / 32;
+  constexpr int KSP = 64 / RB;
+  constexpr int KPW = KS / KSP;  // k32-steps of each source per wave (H = 256: 8 or 16)
+  constexpr int W_BYTES = 16 * GC * 16;
+  constexpr int NW = 2 * L - 1;
+  static_assert(KSP >= L && KS % KSP == 0, "k split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;
+  char* Part = smem + NW * W_BYTES;  // [wave][L] tiles of 1 KB
+  int* s_word = (int*)(Part + 4 * L * 1024);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int rt = wave / KSP, kp = wave % KSP;
+
+  const int info = cluster_join(p.sync, p.seq, s_word);
+  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
+  if (info < 0) return;
+  const int NU = p.NU;
+  const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
+  const int r0 = p.row0 + cluster * p.Mc;
+  const int rend = min(p.row0 + p.nrows, r0 + p.Mc);
+  if (r0 >= rend) return;
+  unsigned* flags = p.sync + kSyncFlags + cluster * 32;
+  const int u0 = me * 16, uq = u0 + q * 4;
+  const int B = p.B, T = p.T;
+  {
+    ClUnitMap um{u0};
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        glds_tile<u16, 16, 64>(Wl + (2 * l) * W_BYTES + kb * 16384, p.w_hh_t[l], G, 0, kb * 512, um, 0, tid);
+        if (l > 0) glds_tile<u16, 16, 64>(Wl + (2 * l - 1) * W_BYTES + kb * 16384, p.w_ih_t[l], G, 0, kb * 512, um, 0, tid);
+      }
+  }
+  const int row = r0 + rt * 16 + r;
+  const int64_t rowc = row < rend ? row : rend - 1;
+  const bool epi = kp < L;  // this wave finishes layer kp of its row tile
+  f32x4 dcreg = f32x4{0.f, 0.f, 0.f, 0.f}, ccur = dcreg, dgs[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) dgs[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto pack4 = [](const f32x4& v) -> uint2 {
+    return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+  };
+  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(p.dg);
+  unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
+  __syncthreads();
+
+  const int nsteps = T + L - 1;
+  for (int s = 0; s < nsteps; ++s) {
+    CL_TLOG(s * 8 + 0);
+    const int t = T - 1 - (s - (L - 1 - kp));  // the time layer kp handles at this step
+    const bool act = epi && t >= 0 && t < T;
+    uint2 gk[4];
+    f32x4 cprev, ext;
+    if (act) {
+      const int64_t lt = (int64_t)kp * T + t;
+      const u16* gp = p.gates + (lt * B + rowc) * G + uq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gk[g] = *(const uint2*)(gp + g * H);
+      if (t == T - 1) ccur = *(const f32x4*)(p.cs + (lt * B + rowc) * H + uq);
+      cprev = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + rowc) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      ext = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kp == L - 1 && p.d_hs_top) ext = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + rowc) * H + uq);
+      if (t == T - 1 && p.d_hn) ext += *(const f32x4*)(p.d_hn + rowc * (L * H) + kp * H + uq);
+    }
+    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
+    CL_TLOG(s * 8 + 1);
+
+    f32x4 acc[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 a[L][KPW];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int tau = T - s + (L - 1 - l);
+      if (s == 0 || tau < 0 || tau > T - 1) continue;
+      const int64_t base = ((((int64_t)l * T + tau) * B + rowc) * G + (kp * KPW * 4 + q) * 8) * 2;
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) a[l][j] = load_sc1(dg_rs, base + j * 64);
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int tau = T - s + (L - 1 - l);
+      if (s == 0 || tau < 0 || tau > T - 1) continue;
+      const bool rec = tau - 1 >= 0;
+      const char* Whh = Wl + (2 * l) * W_BYTES;
+      const char* Wih = Wl + (l > 0 ? 2 * l - 1 : 0) * W_BYTES;
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a[l][j]);
+        const int kc = ((kp * KPW + j) << 2) | q;
+        const int woff = (kc >> 6) * 16384 + kc_off<64>(r, kc & 63);
+        if (rec) acc[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(Whh + woff)), av, acc[l], 0, 0, 0);
+        if (l > 0) {
+          const int ld = l > 0 ? l - 1 : 0;
+          acc[ld] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(Wih + woff)), av, acc[ld], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) *(f32x4*)(Part + (wave * L + l) * 1024 + lane * 16) = acc[l];
+    __syncthreads();
+    CL_TLOG(s * 8 + 2);
+    if (act) {
+      f32x4 dh = ext;
+#pragma unroll
+      for (int k = 0; k < KSP; ++k) dh += *(const f32x4*)(Part + ((rt * KSP + k) * L + kp) * 1024 + lane * 16);
+      const f32x4 ig = unpack4(gk[0]), fg = unpack4(gk[1]), gg = unpack4(gk[2]), og = unpack4(gk[3]);
+      f32x4 dp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float tc = tanhf_(ccur[i]);
+        float dc = dh[i] * og[i] * (1.f - tc * tc);
+        if (t != T - 1) dc += dcreg[i];
+        const float d_o = dh[i] * tc;
+        const float d_i = dc * gg[i], d_f = dc * cprev[i], d_g = dc * ig[i];
+        dcreg[i] = dc * fg[i];
+        dp[0][i] = d_i * ig[i] * (1.f - ig[i]);
+        dp[1][i] = d_f * fg[i] * (1.f - fg[i]);
+        dp[2][i] = d_g * (1.f - gg[i] * gg[i]);
+        dp[3][i] = d_o * og[i] * (1.f - og[i]);
+      }
+      ccur = cprev;
+      if (kp == 0 && p.dgsum) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dgs[g] += dp[g];
+      }
+      if (row < rend) {
+        u16* go = p.dg + (((int64_t)kp * T + t) * B + row) * G + uq;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = pack4(dp[g]);
+      }
+    }
+    CL_TLOG(s * 8 + 3);
+    if (s + 1 < nsteps) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));
+    CL_TLOG(s * 8 + 4);
+  }
+  if (p.dgsum && kp == 0 && row < rend) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *(f32x4*)(p.dgsum + (int64_t)row * G + g * H + uq) = dgs[g];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static bool device_ok() {
@@ -638,11 +952,24 @@ static int launch_fwd_rb(const ClFwd& p, hipStream_t st) {
   return fh_launch_status();
 }
 
+template <int H, int L, int RB>
+static int launch_fwd_ks(const ClFwd& p, hipStream_t st) {
+  constexpr int SMEM = (2 * L - 1) * 64 * (H / 8) * 16 + 4 * L * 4 * 1024 + 16;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_ksplit_kernel<H, L, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((lstm_fwd_ksplit_kernel<H, L, RB>), dim3(kGrid), dim3(kThreads), SMEM, st, p);
+  return fh_launch_status();
+}
+
 template <int H, int L>
 static int launch_fwd(const ClFwd& p, int RB, hipStream_t st) {
   switch (RB) {
-    case 16: return launch_fwd_rb<H, L, 16>(p, st);
-    case 32: return launch_fwd_rb<H, L, 32>(p, st);
+    case 16: return launch_fwd_ks<H, L, 16>(p, st);
+    case 32: return launch_fwd_ks<H, L, 32>(p, st);
     case 64: return launch_fwd_rb<H, L, 64>(p, st);
     default: return launch_fwd_rb<H, L, 128>(p, st);
   }
@@ -684,7 +1011,7 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     p.hs_top_f32 = d->hs_top_f32;
     p.hn = d->hn;
     p.sync = (unsigned*)d->lp;
-    p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES / 2) : nullptr;
+    p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
     p.seq = (int)(row0 / chunk);
     double fl = 0;
     for (int l = 0; l < L; ++l) fl += 2.0 * nrows * 4 * H * ((l > 0 ? d->T * H : 0) + (d->T - 1) * (double)H);
@@ -719,11 +1046,24 @@ static int launch_bwd_rb(const ClBwd& p, hipStream_t st) {
   return fh_launch_status();
 }
 
+template <int H, int L, int RB>
+static int launch_bwd_ks(const ClBwd& p, hipStream_t st) {
+  constexpr int SMEM = (2 * L - 1) * 16 * (4 * H / 8) * 16 + 4 * L * 1024 + 16;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_ksplit_kernel<H, L, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((lstm_bwd_ksplit_kernel<H, L, RB>), dim3(kGrid), dim3(kThreads), SMEM, st, p);
+  return fh_launch_status();
+}
+
 template <int H, int L>
 static int launch_bwd(const ClBwd& p, int RB, hipStream_t st) {
   switch (RB) {
-    case 16: return launch_bwd_rb<H, L, 16>(p, st);
-    case 32: return launch_bwd_rb<H, L, 32>(p, st);
+    case 16: return launch_bwd_ks<H, L, 16>(p, st);
+    case 32: return launch_bwd_ks<H, L, 32>(p, st);
     case 64: return launch_bwd_rb<H, L, 64>(p, st);
     default: return launch_bwd_rb<H, L, 128>(p, st);
   }
@@ -757,7 +1097,7 @@ int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStrea
     p.dg = (u16*)bd->dgates;
     p.dgsum = d->Ic > 0 ? bd->dgsum : nullptr;
     p.sync = (unsigned*)d->lp;
-    p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES / 2) : nullptr;
+    p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
     double fl = 0;
     for (int l = 0; l < L; ++l) fl += 2.0 * nrows * H * ((l < L - 1 ? d->T * 4.0 * H : 0) + (d->T - 1) * 4.0 * H);
     const int ts = trace_begin(st, kTraceBwdCell, fl);

@@ -38,10 +38,11 @@ def _run(hb, x_tm, xc, T, params, g_out, g_hn, cluster):
 
 
 # (B, T, I, Ic, H, L): whole tiles, ragged clusters, a batch smaller than the cluster count, one layer, H = 128,
-# more rows than one launch covers (B > 16 clusters x 128 rows), T = 1
+# more rows than one launch covers, T = 1; B >= 1024 takes the slice form (every wave its own 16 rows)
 CASES = [(256, 20, 80, 0, 256, 2), (100, 7, 80, 32, 256, 2), (16, 5, 0, 64, 256, 2), (5, 3, 80, 0, 256, 2),
          (2048, 20, 80, 0, 256, 2), (300, 6, 40, 0, 128, 2), (64, 4, 80, 0, 256, 1), (2500, 3, 80, 32, 256, 2),
-         (700, 1, 80, 0, 256, 2), (1000, 9, 0, 64, 128, 1)]
+         (700, 1, 80, 0, 256, 2), (1000, 9, 0, 64, 128, 1), (1024, 5, 80, 0, 256, 2), (1500, 4, 80, 32, 128, 2),
+         (4100, 2, 0, 64, 256, 1)]
 
 
 @pytest.mark.parametrize("B,T,I,Ic,H,L", CASES)

@@ -21,7 +21,7 @@ for B in (256, 2048):
             (hs.sum() + hn.sum()).backward()
     torch.cuda.synchronize()
     lp = hb.LSTM_WORKSPACES[-1]
-    log = lp[8192:8192 + 8 * 8 * (T + L - 1)].view(torch.int64).cpu().view(T + L - 1, 8)[:, :5].double() * 0.01  # us
+    log = lp[12288:12288 + 8 * 8 * (T + L - 1)].view(torch.int64).cpu().view(T + L - 1, 8)[:, :5].double() * 0.01  # us
     t0 = log[0, 0]
     print("B=%d  total %.1f us; per step: wait, contraction, gates+h store, publish, [tail stores until next step]" % (B, (log[-1, 4] - t0).item()))
     for s in range(T + L - 1):
