@@ -201,6 +201,8 @@ def main():
         dt = tt.item()
     elbo = (lb.mean() / T).item()
     ok = bool(torch.isfinite(loss).item())
+    if hb.lstm_sync_status() != 0:
+        raise SystemExit("a persistent LSTM recurrence launch gave up (status %d): results invalid" % hb.lstm_sync_status())
 
     roof = None
     if not args.no_roofline:  # every rank runs the instrumented steps (they contain collectives); rank 0 reports
@@ -220,7 +222,9 @@ def main():
         hb.cell_trace(False)
         per_op = hb.OP_TIMER.summary()
         hb.OP_TIMER.disable()
-        names = {0: "lstm_fwd_step_kernel", 1: "lstm_bwd_step_kernel"}
+        form = hb.LAST_LSTM_FORM["form"]  # which schedule the library took for this shape (fhvae_lstm_form)
+        kn = {0: "lstm_%s_step_kernel", 1: "lstm_%s_cluster_kernel", 2: "lstm_%s_ksplit_kernel"}[form]
+        names = {0: kn % "fwd", 1: kn % "bwd"}
         if not cells:  # FC model: no LSTM cells to trace
             cells = {0: (1, 1e-9, 0.0)}
         dom = max(cells, key=lambda k: cells[k][1])
@@ -237,7 +241,7 @@ def main():
                 traffic = None
         roof = None if rank != 0 else {"bound": "mfma", "kernel": "%s<%s>" % (names[dom], args.dtype), "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                "launches_per_step": n / args.steps, "avg_launch_us": t_ms / n * 1e3,
+                "schedule": hb.LSTM_FORMS[form], "launches_per_step": n / args.steps, "avg_launch_us": t_ms / n * 1e3,
                 "flops_per_launch": fl / n,
                 "cells": {names[k]: {"launches_per_step": v[0] / args.steps, "avg_launch_us": v[1] / v[0] * 1e3,
                                      "tflops": v[2] / (v[1] * 1e-3) / 1e12} for k, v in cells.items()},

@@ -121,6 +121,11 @@ typedef struct fhvae_lstm_desc {
 } fhvae_lstm_desc;
 
 int64_t fhvae_lstm_lp_bytes(const fhvae_lstm_desc* d);
+/* Which schedule fhvae_lstm_seq_fwd/_bwd take for this descriptor on the current device: 0 = one launch per wavefront
+   step; 1 = persistent cluster kernel, waves split the batch rows; 2 = persistent cluster kernel, waves split the
+   contraction (small batches).  1 and 2 need the GPU to themselves while they run (256 co-resident workgroups);
+   FHVAE_NO_CLUSTER=1 in the environment forces 0. */
+int fhvae_lstm_form(const fhvae_lstm_desc* d);
 int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream);
 
 typedef struct fhvae_lstm_bwd_desc {

@@ -492,6 +492,11 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
   return FHVAE_OK;
 }
 
+extern "C" int fhvae_lstm_form(const fhvae_lstm_desc* d) {
+  if (!d || check_desc(d) != FHVAE_OK || !cluster_eligible(d)) return 0;
+  return cluster_form(d);
+}
+
 extern "C" int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream) {
   int e = check_desc(d);
   if (e) return e;

@@ -143,6 +143,17 @@ __device__ __forceinline__ void wait_panels(int younger) {
     if (tl && tid == 0) tl[(slot)] = wall_clock64();                                                        \
   } while (0)
 
+// L1-bypassing 16-byte loads of exchanged data into registers (the compiler tracks their vmcnt)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, int64_t byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, kSc1);
+  return uint4{v.x, v.y, v.z, v.w};
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
@@ -235,20 +246,53 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
   };
 
   unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
-  const int nsteps = T + L - 1;
-  for (int s = 0; s < nsteps; ++s) {
-    CL_TLOG(s * 8 + 0);
-    // (1) layer 0's additive term for t = s: independent of the exchange, fetched under the wait
-    f32x4 padd[TM][4];
-    if (s < T && wact) {
+  // what only the backward / the caller reads (c, the activated gates, the f32 copy of the top h): stored after the publish.
+  // (Deferring these stores into the next step's contraction was measured slower: they queue in front of its operand
+  // loads, 246 -> 269 us per net at B = 2048.)
+  uint2 gpk[L][TM][4];  // activated gates, packed bf16
+  f32x4 hreg[L][TM];
+  auto tail_stores = [&](int sp) {
+    if (!wact) return;
+#pragma unroll
+    for (int ll = 0; ll < L; ++ll) {
+      const int t = sp - ll;
+      if (t < 0 || t >= T) continue;
+      const int64_t lt = (int64_t)ll * T + t;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const int row = r0 + wrow0 + tm * 16 + r;
-        const float* pp = p.pre + (int64_t)s * p.pre_tstride + (int64_t)(row < rend ? row : rend - 1) * (4 * H) + uq;
+        if (row >= rend) continue;
+        *(f32x4*)(p.cs + (lt * B + row) * H + uq) = creg[ll][tm];
+        u16* go = p.gates + (lt * B + row) * (4 * H) + uq;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) padd[tm][g] = *(const f32x4*)(pp + g * H);
+        for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = gpk[ll][tm][g];
+        if (ll == L - 1 && p.hs_top_f32) *(f32x4*)(p.hs_top_f32 + ((int64_t)t * B + row) * H + uq) = hreg[ll][tm];
+        if (p.hn && t == T - 1) *(f32x4*)(p.hn + (int64_t)row * (L * H) + ll * H + uq) = hreg[ll][tm];
       }
     }
+  };
+  f32x4 pnext[TM][4];
+  auto load_pre = [&](int t) {
+    if (!wact) return;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = r0 + wrow0 + tm * 16 + r;
+      const float* pp = p.pre + (int64_t)t * p.pre_tstride + (int64_t)(row < rend ? row : rend - 1) * (4 * H) + uq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pnext[tm][g] = *(const f32x4*)(pp + g * H);
+    }
+  };
+  load_pre(0);
+  const int nsteps = T + L - 1;
+  for (int s = 0; s < nsteps; ++s) {
+    CL_TLOG(s * 8 + 0);
+    // (1) layer 0's additive term for t = s was fetched during step s-1 (it comes from HBM: loads return in order, so
+    //     fetching it here would put its latency in front of the flag poll)
+    f32x4 padd[TM][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) padd[tm][g] = pnext[tm][g];
     // (2) h of step s-1 from every member
     if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
 
@@ -311,9 +355,8 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     }
 
     CL_TLOG(s * 8 + 2);
+    if (s + 1 < T) load_pre(s + 1);  // flies under the epilogue
     // (4) gates + cell update for the active layers; h leaves first (it is what the other members wait for)
-    uint2 gpk[L][TM][4];  // activated gates, packed bf16
-    f32x4 hreg[L][TM];
     if (wact) {
 #pragma unroll
       for (int ll = 0; ll < L; ++ll) {
@@ -345,26 +388,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     // (5) publish step s (also the barrier that frees the staging buffers for the next step)
     if (s + 1 < nsteps) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));
     CL_TLOG(s * 8 + 4);
-    // (6) everything only the backward / the caller reads: off the critical path, under the next step's wait
-    if (wact) {
-#pragma unroll
-      for (int ll = 0; ll < L; ++ll) {
-        const int t = s - ll;
-        if (t < 0 || t >= T) continue;
-        const int64_t lt = (int64_t)ll * T + t;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const int row = r0 + wrow0 + tm * 16 + r;
-          if (row >= rend) continue;
-          *(f32x4*)(p.cs + (lt * B + row) * H + uq) = creg[ll][tm];
-          u16* go = p.gates + (lt * B + row) * (4 * H) + uq;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = gpk[ll][tm][g];
-          if (ll == L - 1 && p.hs_top_f32) *(f32x4*)(p.hs_top_f32 + ((int64_t)t * B + row) * H + uq) = hreg[ll][tm];
-          if (p.hn && t == T - 1) *(f32x4*)(p.hn + (int64_t)row * (L * H) + ll * H + uq) = hreg[ll][tm];
-        }
-      }
-    }
+    tail_stores(s);  // (6) off the critical path, under the next step's wait
   }
 }
 
@@ -460,35 +484,39 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
   };
   unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
 
+  // epilogue operands of step `sn`: layer l handles t = T-1 - (sn - (L-1-l))
+  uint2 gk[L][TM][4];
+  f32x4 cprev[L][TM], ext[L][TM];
+  auto load_epi = [&](int sn) {
+    if (!wact) return;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int t = T - 1 - (sn - (L - 1 - l));
+      if (t < 0 || t >= T) continue;
+      const int64_t lt = (int64_t)l * T + t;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row0_ = r0 + wrow0 + tm * 16 + r;
+        const int64_t row = row0_ < rend ? row0_ : rend - 1;
+        const u16* gp = p.gates + (lt * B + row) * G + uq;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gk[l][tm][g] = *(const uint2*)(gp + g * H);
+        if (t == T - 1) ccur[l][tm] = *(const f32x4*)(p.cs + (lt * B + row) * H + uq);
+        cprev[l][tm] = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + row) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (l == L - 1 && p.d_hs_top) e = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + row) * H + uq);
+        if (t == T - 1 && p.d_hn) e += *(const f32x4*)(p.d_hn + row * (L * H) + l * H + uq);
+        ext[l][tm] = e;
+      }
+    }
+  };
   const int nsteps = T + L - 1;
   for (int s = 0; s < nsteps; ++s) {
     CL_TLOG(s * 8 + 0);
-    // (1) the saved activations / cell states / external gradients of this step's (layer, time) pairs: independent
-    //     of the exchange, fetched under the wait.  Layer l handles t = T-1 - (s - (L-1-l)).
-    uint2 gk[L][TM][4];
-    f32x4 cprev[L][TM], ext[L][TM];
-    if (wact) {
-#pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const int t = T - 1 - (s - (L - 1 - l));
-        if (t < 0 || t >= T) continue;
-        const int64_t lt = (int64_t)l * T + t;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const int row0_ = r0 + wrow0 + tm * 16 + r;
-          const int64_t row = row0_ < rend ? row0_ : rend - 1;
-          const u16* gp = p.gates + (lt * B + row) * G + uq;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) gk[l][tm][g] = *(const uint2*)(gp + g * H);
-          if (t == T - 1) ccur[l][tm] = *(const f32x4*)(p.cs + (lt * B + row) * H + uq);
-          cprev[l][tm] = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + row) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
-          f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (l == L - 1 && p.d_hs_top) e = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + row) * H + uq);
-          if (t == T - 1 && p.d_hn) e += *(const f32x4*)(p.d_hn + row * (L * H) + l * H + uq);
-          ext[l][tm] = e;
-        }
-      }
-    }
+    // (1) the saved activations / cell states / external gradients of this step's (layer, time) pairs: independent of
+    //     the exchange, fetched under the wait.  (Fetching them one step ahead, under the previous epilogue, was measured
+    //     slower: 404 -> 448 us per net at B = 2048.)
+    load_epi(s);
     // (2) dg of step s-1 from every member
     if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
     CL_TLOG(s * 8 + 1);
@@ -609,16 +637,6 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
 // them against the stationary weights, the partial tiles are summed through LDS and wave (rt, l) finishes layer l.
 // One L2 round trip for the operand, a quarter of the MFMA / LDS work per wave.
 // ---------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, int64_t byte_off) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, kSc1);
-  return uint4{v.x, v.y, v.z, v.w};
-}
-
 template <int H, int L, int RB>
 __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
   constexpr int HC = H / 8, KS = H / 32;
@@ -981,6 +999,14 @@ static void cluster_rows(int64_t nrows, int NC, int* Mc, int* RB) {
   m = (m + 15) / 16 * 16;
   *Mc = (int)m;
   *RB = m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : 128;
+}
+
+int cluster_form(const fhvae_lstm_desc* d) {
+  const int NC = kGrid / ((int)d->H / 16);
+  const int64_t chunk = (int64_t)NC * 128;
+  int Mc, RB;
+  cluster_rows(d->B < chunk ? d->B : chunk, NC, &Mc, &RB);
+  return RB <= 32 ? 2 : 1;
 }
 
 int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st) {

@@ -80,6 +80,7 @@ SIGNATURES = {
                                                _vp]),
     "fhvae_gauss_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
+    "fhvae_lstm_form": (C.c_int, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
     "fhvae_lstm_seq_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), _vp]),
     "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
@@ -416,6 +417,11 @@ def _fill_lstm_desc(d, dtype, dims, x_tm, xc, params, x_lp=None):
 LSTM_WORKSPACES: list = []
 
 
+LSTM_FORMS = {0: "one launch per wavefront step", 1: "persistent cluster kernel (waves split rows)",
+              2: "persistent cluster kernel (waves split the contraction)"}
+LAST_LSTM_FORM = {"form": 0}
+
+
 def lstm_sync_status() -> int:
     """OR of the status words of the recent bf16 LSTM workspaces (synchronises).  Non-zero: a persistent recurrence
     launch gave up (bounded spin expired / unexpected workgroup placement) and its outputs are invalid."""
@@ -465,7 +471,9 @@ class _LstmSeq(torch.autograd.Function):
             lp = torch.empty(int(lib.fhvae_lstm_lp_bytes(C.byref(d))), device=dev, dtype=torch.uint8)
             LSTM_WORKSPACES.append(lp)
             del LSTM_WORKSPACES[:-16]
+            d.lp = _p(lp)
         d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.pre, d.lp = _p(hs), _p(cs), _p(gates), _p(hn), _p(hs_top), _p(pre), _p(lp)
+        LAST_LSTM_FORM["form"] = int(lib.fhvae_lstm_form(C.byref(d)))
         with _Timed("fhvae_lstm_seq_fwd"):
             _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")
         ctx.dims, ctx.dtype = dims, dtype
