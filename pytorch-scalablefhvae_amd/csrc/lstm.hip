@@ -627,8 +627,10 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
         }
       }
     }
-    e = launch_colsum(dgl, d->dtype, G, bd->db_ih[l], bd->db_hh[l], T_ * B, G, st);
-    if (e) return e;
+    if (!(sizeof(T) == 2 && cluster_eligible(d))) {  // (the persistent backward kernels sum the bias gradients themselves)
+      e = launch_colsum(dgl, d->dtype, G, bd->db_ih[l], bd->db_hh[l], T_ * B, G, st);
+      if (e) return e;
+    }
   }
   return FHVAE_OK;
 }

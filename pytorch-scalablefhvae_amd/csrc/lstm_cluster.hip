@@ -399,6 +399,22 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
 // is dg^l of the previous step (bf16, fresh address per (l,t)): the matrix dg^l_{tau} is at once the recurrent operand
 // of layer l (time tau-1) and the from-above operand of layer l-1 (time tau), so it is staged once.
 // ---------------------------------------------------------------------------------------------
+// column sums for the bias gradients: v holds this lane's partial sums for 4 consecutive units (rows = lane & 15 of its
+// 16-row tiles); add up the 16 row lanes, then one lane per unit quad adds into both bias gradients
+__device__ __forceinline__ void db_reduce_add(f32x4 v, float* db_a, float* db_b, int col, int lane) {
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], off, 64);
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (db_a) atomicAdd(db_a + col + i, v[i]);
+      if (db_b) atomicAdd(db_b + col + i, v[i]);
+    }
+  }
+}
+
 struct ClBwd {
   int B, T, NU, Mc;
   int row0, nrows;
@@ -411,6 +427,8 @@ struct ClBwd {
   const float* d_hn;     // (B,L*H) or NULL
   u16* dg;               // (L,T,B,4H) out
   float* dgsum;          // (B,4H) out: sum over t of layer 0's dg, or NULL
+  float* db_ih[2];       // [4H] bias gradients (accumulated with atomics: += sum over t and rows of dg^l), may be NULL
+  float* db_hh[2];
   unsigned* sync;
   unsigned long long* tlog;
 };
@@ -469,7 +487,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
   }
   const int wrow0 = wave * (TM * 16);
   const bool wact = wrow0 < RB;
-  f32x4 dcreg[L][TM], ccur[L][TM], dgs[TM][4];
+  f32x4 dcreg[L][TM], ccur[L][TM], dgs[L][TM][4];  // dgs: running sums over t of dg (layer 0: also the d_xc operand)
 #pragma unroll
   for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -477,7 +495,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) dgs[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int l = 0; l < L; ++l) dgs[l][tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
   ClRowMap arm{r0, rend - 1};
   auto pack4 = [](const f32x4& v) -> uint2 {
     return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
@@ -602,9 +622,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
             dp[3][i] = d_o * og[i] * (1.f - og[i]);
           }
           ccur[l][tm] = cprev[l][tm];  // c_{t-1} is the next step's c_t
-          if (l == 0 && p.dgsum) {
+          if (row < rend) {  // (padding rows computed from clamped loads must not reach the sums)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dgs[tm][g] += dp[g];
+            for (int g = 0; g < 4; ++g) dgs[l][tm][g] += dp[g];
           }
           if (row < rend) {
             u16* go = p.dg + (lt * B + row) * G + uq;
@@ -625,7 +645,20 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
       const int row = r0 + wrow0 + tm * 16 + r;
       if (row >= rend) continue;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *(f32x4*)(p.dgsum + (int64_t)row * G + g * H + uq) = dgs[tm][g];
+      for (int g = 0; g < 4; ++g) *(f32x4*)(p.dgsum + (int64_t)row * G + g * H + uq) = dgs[0][tm][g];
+    }
+  }
+  if (wact) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      if (!p.db_ih[l] && !p.db_hh[l]) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = dgs[l][0][g];
+#pragma unroll
+        for (int tm = 1; tm < TM; ++tm) v += dgs[l][tm][g];
+        db_reduce_add(v, p.db_ih[l], p.db_hh[l], g * H + uq, lane);
+      }
     }
   }
 }
@@ -914,7 +947,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
         dp[3][i] = d_o * og[i] * (1.f - og[i]);
       }
       ccur = cprev;
-      if (kp == 0 && p.dgsum) {
+      if (row < rend) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) dgs[g] += dp[g];
       }
@@ -931,6 +964,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
   if (p.dgsum && kp == 0 && row < rend) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) *(f32x4*)(p.dgsum + (int64_t)row * G + g * H + uq) = dgs[g];
+  }
+  if (epi && (p.db_ih[kp] || p.db_hh[kp])) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) db_reduce_add(dgs[g], p.db_ih[kp], p.db_hh[kp], g * H + uq, lane);
   }
 }
 
@@ -1122,6 +1159,7 @@ int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStrea
     p.d_hn = bd->d_hn;
     p.dg = (u16*)bd->dgates;
     p.dgsum = d->Ic > 0 ? bd->dgsum : nullptr;
+    for (int l = 0; l < L; ++l) p.db_ih[l] = bd->db_ih[l], p.db_hh[l] = bd->db_hh[l];
     p.sync = (unsigned*)d->lp;
     p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
     double fl = 0;
