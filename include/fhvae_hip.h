@@ -83,6 +83,15 @@ int fhvae_gauss_head_reparam_fwd(const void* h, int64_t ldh, const void* w_mu, c
 int fhvae_gauss_reparam_bwd(const float* d_mu, const float* d_logvar, const float* d_sample,
                             const float* eps, const float* logvar, float* g_mu, float* g_lv,
                             int64_t n, void* stream);
+/* The whole backward of fhvae_gauss_head_reparam_fwd (f32 h) in four launches: g_ws[M,2D] = [g_mu | g_lv] (workspace,
+ * as fhvae_gauss_reparam_bwd computes them), dh[M,K] = g_mu.W_mu + g_lv.W_lv (one two-segment contraction; NULL to
+ * skip), dw_mu/dw_lv[D,K] += g^T.h (one contraction, output split), db_mu/db_lv[D] += column sums of g.
+ * Replaces reparam_bwd + 2 x fhvae_linear_bwd (7 launches) -- GaussianLayer backward, simple_fhvae.py:193-216. */
+int fhvae_gauss_head_bwd(const float* h, int64_t ldh, const float* w_mu, const float* w_lv,
+                         const float* d_mu, const float* d_logvar, const float* d_sample,
+                         const float* eps, const float* logvar, float* g_ws, float* dh, int64_t lddh,
+                         float* dw_mu, float* dw_lv, float* db_mu, float* db_lv, int64_t M, int64_t K,
+                         int64_t D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-layer LSTM over a whole segment (K1), step-fused cells: one launch per wavefront step

@@ -12,7 +12,7 @@ namespace fh {
 __device__ __forceinline__ void gemm_store(const GemmParams& p, int row, int col, float v) {
   if (p.relu) v = fmaxf(v, 0.f);
   if (p.C) {
-    float* c = p.C + (int64_t)row * p.ldc + col;
+    float* c = (p.C2 && row >= p.c_split) ? p.C2 + (int64_t)(row - p.c_split) * p.ldc + col : p.C + (int64_t)row * p.ldc + col;
     if (p.mode == 0)
       *c = v;
     else if (p.mode == 1)
@@ -226,7 +226,7 @@ __global__ void relu_mask_kernel(const float* __restrict__ dy, int64_t lddy, con
 // covers 32 column groups; rows are strided over gridDim.y; 8 row lanes reduce through LDS, then atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, int64_t ldg, float* __restrict__ db,
-                                                     float* __restrict__ db2, int64_t M, int64_t N) {
+                                                     float* __restrict__ db2, int64_t M, int64_t N, int64_t split) {
   constexpr int E = 16 / (int)sizeof(T);
   __shared__ float red[8][32 * E + 1];
   const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -271,12 +271,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, in
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) t += red[r][c];
-    if (db) atomicAdd(db + n, t);
-    if (db2) atomicAdd(db2 + n, t);
+    if (split > 0) {  // two vectors side by side: columns < split -> db, the others -> db2
+      float* d = n < split ? (db ? db + n : nullptr) : (db2 ? db2 + (n - split) : nullptr);
+      if (d) atomicAdd(d, t);
+    } else {
+      if (db) atomicAdd(db + n, t);
+      if (db2) atomicAdd(db2 + n, t);
+    }
   }
 }
 
-int launch_colsum(const void* g, int dtype, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st) {
+int launch_colsum(const void* g, int dtype, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st, int64_t split) {
   if (!db && !db2) return FHVAE_OK;
   const int E = dtype == FHVAE_F32 ? 4 : 8;
   int64_t gx = fh_cdiv(N, 32 * E);
@@ -286,9 +291,9 @@ int launch_colsum(const void* g, int dtype, int64_t ldg, float* db, float* db2, 
   if (gy < 1) gy = 1;
   dim3 grid((unsigned)gx, (unsigned)gy);
   if (dtype == FHVAE_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)g, ldg, db, db2, M, N);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)g, ldg, db, db2, M, N, split);
   else
-    hipLaunchKernelGGL(colsum_kernel<u16>, grid, dim3(256), 0, st, (const u16*)g, ldg, db, db2, M, N);
+    hipLaunchKernelGGL(colsum_kernel<u16>, grid, dim3(256), 0, st, (const u16*)g, ldg, db, db2, M, N, split);
   return fh_launch_status();
 }
 
@@ -308,6 +313,20 @@ __global__ void reparam_bwd_kernel(const float* __restrict__ d_mu, const float* 
   g_mu[i] = (d_mu ? d_mu[i] : 0.f) + ds;
   float e = (d_s && eps) ? ds * eps[i] * 0.5f * expf(0.5f * lv[i]) : 0.f;
   g_lv[i] = (d_lv ? d_lv[i] : 0.f) + e;
+}
+
+// g[M, 2D] = [g_mu | g_lv]: the two linear layers' upstream gradients side by side, so that one contraction / one
+// column sum serves both
+__global__ void reparam_bwd_cat_kernel(const float* __restrict__ d_mu, const float* __restrict__ d_lv,
+                                       const float* __restrict__ d_s, const float* __restrict__ eps,
+                                       const float* __restrict__ lv, float* __restrict__ g, int64_t n, int D) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t m = i / D, c = i - m * D;
+  float ds = d_s ? d_s[i] : 0.f;
+  float e = (d_s && eps) ? ds * eps[i] * 0.5f * expf(0.5f * lv[i]) : 0.f;
+  g[m * 2 * D + c] = (d_mu ? d_mu[i] : 0.f) + ds;
+  g[m * 2 * D + D + c] = (d_lv ? d_lv[i] : 0.f) + e;
 }
 
 }  // namespace fh
@@ -432,4 +451,57 @@ extern "C" int fhvae_gauss_reparam_bwd(const float* d_mu, const float* d_logvar,
   hipLaunchKernelGGL(reparam_bwd_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, d_mu, d_logvar,
                      d_sample, eps, logvar, g_mu, g_lv, n);
   return fh_launch_status();
+}
+
+extern "C" int fhvae_gauss_head_bwd(const float* h, int64_t ldh, const float* w_mu, const float* w_lv, const float* d_mu,
+                                    const float* d_logvar, const float* d_sample, const float* eps, const float* logvar,
+                                    float* g_ws, float* dh, int64_t lddh, float* dw_mu, float* dw_lv, float* db_mu,
+                                    float* db_lv, int64_t M, int64_t K, int64_t D, void* stream) {
+  FH_CHECK_PTR(g_ws);
+  FH_CHECK_POS(M);
+  FH_CHECK_POS(K);
+  FH_CHECK_POS(D);
+  FH_CHECK_I32(M);
+  FH_CHECK_I32(K);
+  FH_CHECK_I32(2 * D);
+  if (d_sample && (!eps || !logvar)) return FHVAE_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = M * D;
+  hipLaunchKernelGGL(reparam_bwd_cat_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, d_mu, d_logvar, d_sample, eps,
+                     logvar, g_ws, n, (int)D);
+  int e = fh_launch_status();
+  if (e) return e;
+  if (dh) {  // dh[M,K] = g_mu . W_mu + g_lv . W_lv: two K-segments of one contraction, the weights as KM operands
+    FH_CHECK_PTR(w_mu);
+    FH_CHECK_PTR(w_lv);
+    GemmParams p = {};
+    p.seg[0] = Seg{g_ws, 2 * D, 1, w_mu, K, 0, (int)D};
+    p.seg[1] = Seg{g_ws + D, 2 * D, 1, w_lv, K, 0, (int)D};
+    p.M = (int)M;
+    p.N = (int)K;
+    p.C = dh;
+    p.ldc = lddh;
+    p.splitk = 1;
+    e = launch_gemm(p, FHVAE_F32, st);
+    if (e) return e;
+  }
+  if (dw_mu || dw_lv) {  // [dw_mu; dw_lv][2D,K] += g^T . h: one contraction over the M rows, output rows split at D
+    FH_CHECK_PTR(h);
+    FH_CHECK_PTR(dw_mu);
+    FH_CHECK_PTR(dw_lv);
+    GemmParams p = {};
+    p.seg[0] = Seg{g_ws, 2 * D, 0, h, ldh, 0, (int)M};
+    p.M = (int)(2 * D);
+    p.N = (int)K;
+    p.C = dw_mu;
+    p.C2 = dw_lv;
+    p.c_split = (int)D;
+    p.ldc = K;
+    p.mode = 1;
+    p.splitk = 0;
+    e = launch_gemm(p, FHVAE_F32, st);
+    if (e) return e;
+  }
+  if (db_mu || db_lv) return launch_colsum(g_ws, FHVAE_F32, 2 * D, db_mu, db_lv, M, 2 * D, st, D);
+  return FHVAE_OK;
 }

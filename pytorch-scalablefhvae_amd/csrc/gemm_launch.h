@@ -8,6 +8,8 @@ struct GemmParams {
   Seg seg[2];
   int M, N;
   float* C;        // f32 output [M,N] (may be NULL if Clp given)
+  float* C2;       // optional: output rows >= c_split go to C2[(row - c_split), :] (two matrices stacked along M)
+  int c_split;
   int64_t ldc;
   u16* Clp;        // optional bf16 copy of the output
   int64_t ldclp;
@@ -20,6 +22,8 @@ struct GemmParams {
 
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t st);
 int pick_splitk(int64_t M, int64_t N, int64_t K);
-int launch_colsum(const void* g, int dtype, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st);
+// split == 0: db and db2 both receive all N column sums; split > 0: columns < split -> db, the others -> db2
+int launch_colsum(const void* g, int dtype, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st,
+                  int64_t split = 0);
 
 }  // namespace fh

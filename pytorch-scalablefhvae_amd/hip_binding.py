@@ -79,6 +79,7 @@ SIGNATURES = {
     "fhvae_gauss_head_reparam_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int,
                                                _vp]),
     "fhvae_gauss_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "fhvae_gauss_head_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_form": (C.c_int, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
@@ -363,19 +364,23 @@ class _GaussHead(torch.autograd.Function):
         if eps is None:
             d_s = None
         M, D = lv.shape
-        g_mu = torch.empty_like(lv)
-        g_lv = torch.empty_like(lv)
+        K = h.shape[1]
         d_mu = _f32c(d_mu) if d_mu is not None else None
         d_lv = _f32c(d_lv) if d_lv is not None else None
         d_s = _f32c(d_s) if d_s is not None else None
-        with _Timed("fhvae_gauss_reparam_bwd"):
-            _check(lib.fhvae_gauss_reparam_bwd(_p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), _p(g_mu), _p(g_lv), M * D, _stream()),
-                   "fhvae_gauss_reparam_bwd")
         need_dh = ctx.needs_input_grad[0]
         sk = ctx.sinks
-        dh, dw_mu, db_mu = raw_linear_bwd(h, w_mu, None, g_mu, False, need_dx=need_dh, dw_sink=sk[0], db_sink=sk[1])
-        _, dw_lv, db_lv = raw_linear_bwd(h, w_lv, None, g_lv, False, need_dx=need_dh, dx_out=dh if need_dh else None,
-                                         dw_sink=sk[2], db_sink=sk[3])
+        # gradient accumulators: the optimizer's sinks when present (FusedAdam arena), else fresh zeros returned to autograd
+        outs = [k if k is not None else torch.zeros(shape, device=h.device, dtype=torch.float32)
+                for k, shape in zip(sk, ((D, K), (D,), (D, K), (D,)))]
+        dw_mu, db_mu, dw_lv, db_lv = outs
+        g_ws = torch.empty(M, 2 * D, device=h.device, dtype=torch.float32)
+        dh = torch.empty(M, K, device=h.device, dtype=torch.float32) if need_dh else None
+        with _Timed("fhvae_gauss_head_bwd"):
+            _check(lib.fhvae_gauss_head_bwd(_p(h), h.stride(0), _p(w_mu), _p(w_lv), _p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv),
+                                            _p(g_ws), _p(dh), K, _p(dw_mu), _p(dw_lv), _p(db_mu), _p(db_lv), M, K, D, _stream()),
+                   "fhvae_gauss_head_bwd")
+        dw_mu, db_mu, dw_lv, db_lv = (None if k is not None else o for k, o in zip(sk, outs))
         return dh, dw_mu, db_mu, dw_lv, db_lv, None
 
 
