@@ -415,13 +415,19 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
   const int L = d->L;
   const int64_t K0 = I + Ic;
   const T* w0 = op.w_ih[0];
-  // ---- layer-0 input projection (+ both biases): pre = [x_t || xc] . W_ih0^T + b_ih0 + b_hh0
-  {
+  // ---- layer-0 input projection (+ both biases): pre = [x_t || xc] . W_ih0^T + b_ih0 + b_hh0.  The persistent kernels
+  //      multiply x_t themselves when they can (fold): then only the time-constant part is left for this GEMM
+  bool cluster = false, fold = false;
+  if constexpr (sizeof(T) == 2) {
+    cluster = cluster_eligible(d);
+    fold = cluster && cluster_can_fold(d);
+  }
+  if (!(fold && Ic == 0)) {
     GemmParams p = {};
     int s = 0;
-    if (I > 0) p.seg[s++] = Seg{op.x, I, 1, w0, K0, 1, (int)I, 0};
-    if (Ic > 0) p.seg[s++] = Seg{op.xc, Ic, 1, w0 + I, K0, 1, (int)Ic, I > 0 ? (int)B : 0};
-    p.M = (int)(I > 0 ? T_ * B : B);
+    if (I > 0 && !fold) p.seg[s++] = Seg{op.x, I, 1, w0, K0, 1, (int)I, 0};
+    if (Ic > 0) p.seg[s++] = Seg{op.xc, Ic, 1, w0 + I, K0, 1, (int)Ic, (I > 0 && !fold) ? (int)B : 0};
+    p.M = (int)((I > 0 && !fold) ? T_ * B : B);
     p.N = (int)(4 * H);
     p.C = d->pre;
     p.ldc = 4 * H;
@@ -432,9 +438,10 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     if (e) return e;
   }
   if constexpr (sizeof(T) == 2) {
-    if (cluster_eligible(d)) {  // persistent form: the whole recurrence in one launch (lstm_cluster.hip)
+    if (cluster) {  // persistent form: the whole recurrence in one launch (lstm_cluster.hip)
       ClusterWeights cw = {};
       for (int l = 0; l < L; ++l) cw.w_ih[l] = op.w_ih[l], cw.w_hh[l] = op.w_hh[l], cw.w_ih_t[l] = op.w_ih_t[l], cw.w_hh_t[l] = op.w_hh_t[l];
+      cw.x_fold = fold ? (const u16*)op.x : nullptr;
       return cluster_fwd(d, cw, st);
     }
   }

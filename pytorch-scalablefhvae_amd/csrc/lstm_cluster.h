@@ -20,12 +20,15 @@ struct ClusterWeights {  // bf16 operand copies in the workspace
   const u16* w_hh[FHVAE_MAX_LAYERS];    // [4H, H]
   const u16* w_ih_t[FHVAE_MAX_LAYERS];  // [H, 4H]   (l >= 1)
   const u16* w_hh_t[FHVAE_MAX_LAYERS];  // [H, 4H]
+  const u16* x_fold;                    // (T,B,I) bf16 when the forward kernels do the layer-0 input projection themselves
 };
 
 // whether this device / shape can run the cluster kernels (gfx950 with 256 CUs, bf16, H in {128, 256}, L <= 2, ...)
 bool cluster_eligible(const fhvae_lstm_desc* d);
 // 1: the waves of a workgroup split the cluster's rows, 2: they split the contraction (<= 32 rows per cluster)
 int cluster_form(const fhvae_lstm_desc* d);
+// the forward kernels can multiply x_t by W_ih[0][:, :I] themselves (I a multiple of 8, at most 128, rows 16-byte aligned)
+bool cluster_can_fold(const fhvae_lstm_desc* d);
 // the recurrence of fhvae_lstm_seq_fwd after the layer-0 input projection (d->pre filled): all T steps, all layers
 int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st);
 // the recurrence of fhvae_lstm_seq_bwd: fills dgates (and dgsum when Ic > 0)

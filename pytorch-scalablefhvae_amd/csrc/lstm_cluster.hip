@@ -165,8 +165,13 @@ struct ClFwd {
   const u16* w_hh[2];
   const float* b_ih[2];
   const float* b_hh[2];
-  const float* pre;  // layer-0 input projection incl. biases: (T,B,4H), or (B,4H) with pre_tstride = 0
+  const float* pre;  // layer-0 additive term incl. biases: (T,B,4H), or (B,4H) with pre_tstride = 0, or NULL (= biases)
   int64_t pre_tstride;
+  // folded input projection (x != NULL): the kernels multiply x_t (T,B,I) bf16 by this member's rows of W_ih[0][:, :I]
+  // themselves (fragments stationary in registers); `pre` then only holds the time-constant part
+  const u16* x;
+  const u16* w_ih0;  // [4H,K0] bf16
+  int I, K0;
   u16* hs;     // (L,T,B,H)
   float* cs;   // (L,T,B,H)
   u16* gates;  // (L,T,B,4H)
@@ -233,6 +238,10 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
       if (l > 0) bias[l][g] = *(const f32x4*)(p.b_ih[l] + g * H + uq) + *(const f32x4*)(p.b_hh[l] + g * H + uq);
     }
 
+  if (!p.pre) {  // no time-constant input: layer 0's additive term is its two biases
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[0][g] = *(const f32x4*)(p.b_ih[0] + g * H + uq) + *(const f32x4*)(p.b_hh[0] + g * H + uq);
+  }
   const int wrow0 = wave * (TM * 16);       // first cluster row of this wave
   const bool wact = wrow0 < RB;             // waves beyond the tile only help staging
   f32x4 creg[L][TM];
@@ -272,27 +281,63 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     }
   };
   f32x4 pnext[TM][4];
+  const bool pvar = p.pre && p.pre_tstride != 0;  // a different additive term every step (unfolded input projection)
   auto load_pre = [&](int t) {
-    if (!wact) return;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int row = r0 + wrow0 + tm * 16 + r;
       const float* pp = p.pre + (int64_t)t * p.pre_tstride + (int64_t)(row < rend ? row : rend - 1) * (4 * H) + uq;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) pnext[tm][g] = *(const f32x4*)(pp + g * H);
+      for (int g = 0; g < 4; ++g) pnext[tm][g] = (wact && p.pre) ? *(const f32x4*)(pp + g * H) : bias[0][g];
     }
   };
   load_pre(0);
+  // folded input projection: this member's W_ih[0] fragments (gate g, k-step j) stay in registers for the whole launch;
+  // the x fragments of step s+1 are fetched under the epilogue of step s (x comes from HBM, like `pre`)
+  constexpr int KSX = 4;  // up to 128 input features
+  const bool fold = p.x != nullptr;
+  const int nkx = fold ? (p.I + 31) / 32 : 0, nchx = p.I / 8;
+  uint4 wx[4][KSX], xn[TM][KSX];
+#pragma unroll
+  for (int j = 0; j < KSX; ++j) {
+    const int c = j * 4 + q;
+    const bool ok = fold && c < nchx;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (ok) v = *(const uint4*)(p.w_ih0 + (int64_t)(g * H + u0 + r) * p.K0 + c * 8);
+      wx[g][j] = v;
+    }
+  }
+  auto load_x = [&](int t) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = r0 + wrow0 + tm * 16 + r;
+      const u16* xp = p.x + ((int64_t)t * B + (row < rend ? row : rend - 1)) * p.I;
+#pragma unroll
+      for (int j = 0; j < KSX; ++j) {
+        const int c = j * 4 + q;
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (fold && wact && c < nchx) v = *(const uint4*)(xp + c * 8);
+        xn[tm][j] = v;
+      }
+    }
+  };
+  load_x(0);
   const int nsteps = T + L - 1;
   for (int s = 0; s < nsteps; ++s) {
     CL_TLOG(s * 8 + 0);
     // (1) layer 0's additive term for t = s was fetched during step s-1 (it comes from HBM: loads return in order, so
     //     fetching it here would put its latency in front of the flag poll)
     f32x4 padd[TM][4];
+    uint4 xc[TM][KSX];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) padd[tm][g] = pnext[tm][g];
+#pragma unroll
+      for (int j = 0; j < KSX; ++j) xc[tm][j] = xn[tm][j];
+    }
     // (2) h of step s-1 from every member
     if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
 
@@ -311,6 +356,18 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     };
     if (wact) {
       for (int n = 0; n < kRing - 1 && n < npan; ++n) issue(n);
+      if (fold && s < T) {  // layer 0's input projection for t = s, while the first panels are landing
+#pragma unroll
+        for (int j = 0; j < KSX; ++j) {
+          if (j >= nkx) break;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+              acc[0][tm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx[g][j]), __builtin_bit_cast(bf16x8, xc[tm][j]),
+                                                                      acc[0][tm][g], 0, 0, 0);
+        }
+      }
       for (int n = 0; n < npan; ++n) {
         wait_panels(npan - 1 - n < kRing - 2 ? npan - 1 - n : kRing - 2);  // panel n has landed
         if (n + kRing - 1 < npan) issue(n + kRing - 1);  // into the slot consumed one iteration ago
@@ -355,7 +412,10 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     }
 
     CL_TLOG(s * 8 + 2);
-    if (s + 1 < T) load_pre(s + 1);  // flies under the epilogue
+    if (s + 1 < T) {  // fly under the epilogue
+      if (pvar) load_pre(s + 1);
+      if (fold) load_x(s + 1);
+    }
     // (4) gates + cell update for the active layers; h leaves first (it is what the other members wait for)
     if (wact) {
 #pragma unroll
@@ -712,12 +772,38 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     bias[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (epi && kp > 0) bias[g] = *(const f32x4*)(p.b_ih[kp] + g * H + uq) + *(const f32x4*)(p.b_hh[kp] + g * H + uq);
+    if (epi && (kp > 0 || !p.pre)) bias[g] = *(const f32x4*)(p.b_ih[kp] + g * H + uq) + *(const f32x4*)(p.b_hh[kp] + g * H + uq);
   }
   f32x4 creg = f32x4{0.f, 0.f, 0.f, 0.f};
   auto pack4 = [](const f32x4& v) -> uint2 {
     return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
   };
+  // folded input projection: W_ih[0] fragments of this wave's k-steps (j = kp, kp + KSP, ...) stay in registers
+  constexpr int KSXW = (4 + KSP - 1) / KSP;  // up to 128 input features
+  const bool fold = p.x != nullptr;
+  const int nchx = p.I / 8;
+  uint4 wx[4][KSXW];
+#pragma unroll
+  for (int jj = 0; jj < KSXW; ++jj) {
+    const int c = (kp + jj * KSP) * 4 + q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (fold && c < nchx) v = *(const uint4*)(p.w_ih0 + (int64_t)(g * H + u0 + r) * p.K0 + c * 8);
+      wx[g][jj] = v;
+    }
+  }
+  uint4 xn[KSXW];
+  auto load_x = [&](int t) {
+#pragma unroll
+    for (int jj = 0; jj < KSXW; ++jj) {
+      const int c = (kp + jj * KSP) * 4 + q;
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (fold && c < nchx) v = *(const uint4*)(p.x + ((int64_t)t * B + rowc) * p.I + c * 8);
+      xn[jj] = v;
+    }
+  };
+  load_x(0);
   const __amdgpu_buffer_rsrc_t hs_rs = make_rsrc(p.hs);
   unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
   __syncthreads();  // weights have landed
@@ -726,11 +812,14 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
   for (int s = 0; s < nsteps; ++s) {
     CL_TLOG(s * 8 + 0);
     f32x4 padd[4];
-    if (kp == 0 && s < T) {
+    if (kp == 0 && s < T && p.pre) {
       const float* pp = p.pre + (int64_t)s * p.pre_tstride + rowc * (4 * H) + uq;
 #pragma unroll
       for (int g = 0; g < 4; ++g) padd[g] = *(const f32x4*)(pp + g * H);
     }
+    uint4 xc[KSXW];  // this wave's k-steps of x_s (folded input projection), fetched during step s-1
+#pragma unroll
+    for (int jj = 0; jj < KSXW; ++jj) xc[jj] = xn[jj];
     if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
     CL_TLOG(s * 8 + 1);
 
@@ -748,6 +837,14 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
     for (int l = 0; l < L; ++l)
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[l][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (fold && s < T) {
+#pragma unroll
+      for (int jj = 0; jj < KSXW; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx[g][jj]), __builtin_bit_cast(bf16x8, xc[jj]), acc[0][g], 0,
+                                                              0, 0);
+    }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const int tau = s - l - 1;
@@ -775,6 +872,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
         }
       }
     }
+    if (s + 1 < T) load_x(s + 1);  // (HBM: must not sit in front of the next flag poll)
     // partial tiles -> LDS, then wave (rt, l) sums the KSP parts of layer l
 #pragma unroll
     for (int l = 0; l < L; ++l)
@@ -790,7 +888,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
       f32x4 gv[4], c;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        gv[g] = kp == 0 ? padd[g] : bias[g];
+        gv[g] = (kp == 0 && p.pre) ? padd[g] : bias[g];
 #pragma unroll
         for (int k = 0; k < KSP; ++k) gv[g] += *(const f32x4*)(Part + (((rt * KSP + k) * L + kp) * 4 + g) * 1024 + lane * 16);
       }
@@ -1038,6 +1136,10 @@ static void cluster_rows(int64_t nrows, int NC, int* Mc, int* RB) {
   *RB = m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : 128;
 }
 
+bool cluster_can_fold(const fhvae_lstm_desc* d) {
+  return d->I > 0 && d->I % 8 == 0 && d->I <= 128 && (d->I + d->Ic) % 8 == 0 && !getenv("FHVAE_NO_FOLD");
+}
+
 int cluster_form(const fhvae_lstm_desc* d) {
   const int NC = kGrid / ((int)d->H / 16);
   const int64_t chunk = (int64_t)NC * 128;
@@ -1066,8 +1168,17 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
       p.b_ih[l] = d->b_ih[l];
       p.b_hh[l] = d->b_hh[l];
     }
-    p.pre = d->pre;
-    p.pre_tstride = d->I > 0 ? d->B * 4 * d->H : 0;
+    if (w.x_fold) {  // lstm.hip has left only the time-constant part (or nothing) in d->pre
+      p.x = w.x_fold;
+      p.w_ih0 = w.w_ih[0];
+      p.I = (int)d->I;
+      p.K0 = (int)(d->I + d->Ic);
+      p.pre = d->Ic > 0 ? d->pre : nullptr;
+      p.pre_tstride = 0;
+    } else {
+      p.pre = d->pre;
+      p.pre_tstride = d->I > 0 ? d->B * 4 * d->H : 0;
+    }
     p.hs = (u16*)d->hs;
     p.cs = d->cs;
     p.gates = (u16*)d->gates;
