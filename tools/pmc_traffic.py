@@ -38,9 +38,11 @@ def main():
     path = os.path.join(root, "profiles", "pmc_traffic.json")
     res = json.load(open(path)) if os.path.exists(path) else {}
     tname = {"bf16": "unsigned short", "f32": "float"}[dtype]
-    for short in ("lstm_fwd_step_kernel", "lstm_bwd_step_kernel"):
-        f = [(k, v) for k, v in fe.items() if short in k and tname in k]
-        w = [(k, v) for k, v in wr.items() if short in k and tname in k]
+    for short in ("lstm_fwd_step_kernel", "lstm_bwd_step_kernel", "lstm_fwd_cluster_kernel", "lstm_bwd_cluster_kernel",
+                  "lstm_fwd_ksplit_kernel", "lstm_bwd_ksplit_kernel"):
+        typed = "step_kernel" in short  # the persistent kernels are bf16 only (no element type in their names)
+        f = [(k, v) for k, v in fe.items() if short in k and (tname in k or not typed)]
+        w = [(k, v) for k, v in wr.items() if short in k and (tname in k or not typed)]
         if not f or not w:
             continue
         fn, fv = f[0][1]
