@@ -100,6 +100,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    # stdout carries exactly ONE line (the JSON record): libraries that print banners to fd 1 (RCCL prints its version
+    # block there on communicator creation) are sent to stderr for the whole run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,7 +295,8 @@ def main():
             rec["alt_batch"] = alt
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(cfg, B)
-        print(json.dumps(rec))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
     if use_dist:
         import torch.distributed as dist
 

@@ -233,7 +233,12 @@ class DistributedFHVAE:
     def _on_lstm_bwd_done(self, sinks):
         """Fired by hip_binding at the end of an LSTM net's backward: that net's Gaussian head ran earlier in the
         backward pass, so the whole bucket is final -> start its all-reduce now."""
-        if not self.overlap or not sinks or sinks[0] is None:
+        import hip_binding as hb
+
+        # The persistent LSTM kernels need all 256 CUs co-resident: a collective kernel spinning on its peers next to
+        # them would hold some of those CUs for as long as the slowest rank takes.  With that schedule the gradients are
+        # reduced after the backward instead, in one collective over the whole arena (_reduce_gradients).
+        if not self.overlap or not sinks or sinks[0] is None or hb.LAST_LSTM_FORM["form"] != 0:
             return
         g = self._bucket_of_ptr.get(sinks[0].data_ptr())
         if g is None or g in self._pending:
@@ -244,6 +249,11 @@ class DistributedFHVAE:
 
     def _reduce_gradients(self):
         flat = self.opt_nets.flat_grad()
+        if not self._pending and self._buckets:  # nothing in flight: one collective over the contiguous buckets
+            b, e = self._buckets[0][0], self._buckets[-1][1]
+            if e > b:
+                self.sh.all_reduce_(flat[b:e])
+            return
         for g, (b, e) in enumerate(self._buckets):
             if g in self._pending:
                 if self._pending[g] is not None:

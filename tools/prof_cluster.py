@@ -7,7 +7,7 @@ import torch
 import hip_binding as hb
 
 H, L, T, I = 256, 2, 20, 80
-for B in (256, 2048):
+for B in [int(b) for b in os.environ.get("PROF_B", "256,2048").split(",")]:
     torch.manual_seed(0)
     lstm = torch.nn.LSTM(I, H, L)
     names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
