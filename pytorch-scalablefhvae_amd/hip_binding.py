@@ -336,6 +336,7 @@ class _GaussHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w_mu, b_mu, w_lv, b_lv, eps):
         _need_gpu(h, w_mu, b_mu, w_lv, b_lv, eps)
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None in backward (no zero tensors, no reads of them)
         lib = load_library()
         ctx.sinks = tuple(_sink(t) for t in (w_mu, b_mu, w_lv, b_lv))
         h, w_mu, b_mu, w_lv, b_lv = _f32c(h), _f32c(w_mu), _f32c(b_mu), _f32c(w_lv), _f32c(b_lv)
@@ -444,6 +445,7 @@ class _LstmSeq(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_tm, xc, T, dtype, *params):
         lib = load_library()
+        ctx.set_materialize_grads(False)  # encoders use only hn, the decoder only hs_top: the other gradient stays None
         _need_gpu(x_tm, xc, *params)
         L = len(params) // 4
         assert len(params) == 4 * L and 1 <= L <= MAX_LAYERS
@@ -603,6 +605,7 @@ class _Elbo(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2, num_segs, layout, reference_detach):
         _need_gpu(x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2)
+        ctx.set_materialize_grads(False)  # the loss uses lower_bound only; the four reporting outputs carry no gradient
         lib = load_library()
         B, T, F_, xs, xos = layout
         ts = [_f32c(t) for t in (x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2)]
