@@ -4,6 +4,8 @@
 // simple_fhvae.py:193-216.
 #include "gemm_launch.h"
 
+#include <cstdlib>
+
 namespace fh {
 
 // ---------------------------------------------------------------------------------------------
@@ -23,33 +25,13 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, int row, int col
   if (p.Clp) p.Clp[(int64_t)row * p.ldclp + col] = f2bf(v);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool DMA = false>
-__global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
+// one output tile (bx, by) of problem p, K slice bz of p.splitk
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool DMA>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, int bx, int by, int bz, char* smem) {
   using TL = Tile<T, BM, BN, WM, WN, CH>;
   constexpr int TM = TL::TM, TN = TL::TN;
-  // LDS-DMA main loop for interior KC/KC tiles without split-K.  A separate instantiation (it needs 128 KB of LDS for
-  // its two buffers): launched only for small grids, where one workgroup per CU is all there is and the latency of a
-  // panel is the whole cost (256x1024x512 bf16: 8.1 -> 7.0 us); larger grids prefer 2+ workgroups per CU.
   constexpr bool kDma = DMA && AKC && BKC;
   constexpr int NBUF = CH >= 32 ? 2 : 1;
-  using GT = GldsTile<T, BM, BN, WM, WN, CH, NBUF>;
-  __shared__ __attribute__((aligned(16))) char smem[(kDma && GT::SMEM > TL::SMEM) ? GT::SMEM : TL::SMEM];
-  // XCD-aware tile order (guide T1, bijective form): workgroups are dealt round-robin over the 8 XCDs by linear id;
-  // remap so that each XCD owns a CONTIGUOUS range of logical tiles (x fastest, then y, then the K slice): tiles that
-  // share an operand panel then share one private L2 (a split-K weight gradient: one K slice per XCD instead of
-  // every slice fetched by 4-8 XCDs; performance only, any placement is correct).
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  {
-    const int gx = gridDim.x, gy = gridDim.y, nb = gx * gy * (int)gridDim.z;
-    if (nb >= 16) {
-      const int lin = bx + gx * (by + gy * bz);
-      const int q = nb >> 3, r = nb & 7, xcd = lin & 7;
-      const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-      bx = logical % gx;
-      by = (logical / gx) % gy;
-      bz = logical / (gx * gy);
-    }
-  }
   const int m0 = by * BM, n0 = bx * BN;
   const int nkb = num_kblocks<T, CH>(p.seg);
   // split-K: contiguous ranges of panels per z-slice
@@ -90,6 +72,50 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
         if (row < p.M) gemm_store(p, row, col, acc[tm][tn][r] + add);
       }
     }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool DMA = false>
+__global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
+  using TL = Tile<T, BM, BN, WM, WN, CH>;
+  // LDS-DMA main loop for interior KC/KC tiles without split-K.  A separate instantiation (it needs 128 KB of LDS for
+  // its two buffers): launched only for small grids, where one workgroup per CU is all there is and the latency of a
+  // panel is the whole cost (256x1024x512 bf16: 8.1 -> 7.0 us); larger grids prefer 2+ workgroups per CU.
+  constexpr bool kDma = DMA && AKC && BKC;
+  constexpr int NBUF = CH >= 32 ? 2 : 1;
+  using GT = GldsTile<T, BM, BN, WM, WN, CH, NBUF>;
+  __shared__ __attribute__((aligned(16))) char smem[(kDma && GT::SMEM > TL::SMEM) ? GT::SMEM : TL::SMEM];
+  // XCD-aware tile order (guide T1, bijective form): workgroups are dealt round-robin over the 8 XCDs by linear id;
+  // remap so that each XCD owns a CONTIGUOUS range of logical tiles (x fastest, then y, then the K slice): tiles that
+  // share an operand panel then share one private L2 (a split-K weight gradient: one K slice per XCD instead of
+  // every slice fetched by 4-8 XCDs; performance only, any placement is correct).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, nb = gx * gy * (int)gridDim.z;
+    if (nb >= 16) {
+      const int lin = bx + gx * (by + gy * bz);
+      const int q = nb >> 3, r = nb & 7, xcd = lin & 7;
+      const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+      bx = logical % gx;
+      by = (logical / gx) % gy;
+      bz = logical / (gx * gy);
+    }
+  }
+  gemm_tile<T, BM, BN, WM, WN, CH, AKC, BKC, DMA>(p, bx, by, bz, smem);
+}
+
+// Several independent problems of one shape class in ONE launch (blockIdx.z selects problem and K slice): the weight
+// gradients of a net, the two linear layers of a Gaussian head.  At small batches each of them is a latency-bound launch
+// of a few workgroups; together they fill the chip once.
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC>
+__global__ __launch_bounds__(kThreads) void gemm_group_kernel(GemmGroup g) {
+  using TL = Tile<T, BM, BN, WM, WN, CH>;
+  __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
+  int i = 0, bz = blockIdx.z;
+  while (i + 1 < g.n && bz >= g.zbase[i + 1]) ++i;
+  bz -= g.zbase[i];
+  const GemmParams& p = g.p[i];
+  if ((int)blockIdx.y * BM >= p.M || (int)blockIdx.x * BN >= p.N) return;
+  gemm_tile<T, BM, BN, WM, WN, CH, AKC, BKC, false>(p, blockIdx.x, blockIdx.y, bz, smem);
 }
 
 // Scalar fallback for shapes that break the 16-byte staging preconditions (odd K / leading dimension /
@@ -203,6 +229,78 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
     else
       launch_fast<u16, 64, 64, 32>(p, grid, st);
   }
+  return fh_launch_status();
+}
+
+// n <= kMaxGroup problems in one launch when they share dtype, orientation and the 64x64 / 512-byte-panel configuration
+// and take the branch-free staging path; otherwise (and for n == 1) one launch each.  splitk == 0 (auto) is resolved per
+// problem against the group's total tile count.
+int launch_gemm_group(const GemmParams* ps, int n, int dtype, hipStream_t st) {
+  if (n <= 0) return FHVAE_OK;
+  const bool bf = dtype == FHVAE_BF16;
+  const int epc = bf ? 8 : 4;
+  bool ok = n > 1 && n <= kMaxGroup && !getenv("FHVAE_NO_GROUP");
+  int akc = -1, bkc = -1;
+  int64_t tiles = 0;
+  for (int i = 0; i < n && ok; ++i) {
+    const GemmParams& p = ps[i];
+    if (p.M <= 0 || p.N <= 0) return FHVAE_ERR_SHAPE;
+    const bool fast = bf ? (seg_fast_ok<u16>(p.seg[0], p.M, p.N) && seg_fast_ok<u16>(p.seg[1], p.M, p.N))
+                         : (seg_fast_ok<float>(p.seg[0], p.M, p.N) && seg_fast_ok<float>(p.seg[1], p.M, p.N));
+    const int kmax = p.seg[0].K > p.seg[1].K ? p.seg[0].K : p.seg[1].K;
+    const int a = p.seg[0].K > 0 ? p.seg[0].a_kc : p.seg[1].a_kc, b = p.seg[0].K > 0 ? p.seg[0].b_kc : p.seg[1].b_kc;
+    if (p.seg[0].K > 0 && p.seg[1].K > 0 && (p.seg[0].a_kc != p.seg[1].a_kc || p.seg[0].b_kc != p.seg[1].b_kc)) ok = false;
+    if (!fast || kmax <= 16 * epc || (p.splitk == 0 && p.mode != 1)) ok = false;
+    if (p.seg[0].K + p.seg[1].K > 16384) ok = false;  // long contractions are bandwidth-bound: separate launches with the
+                                                       // XCD-aware tile order measured faster (B = 2048: 616k vs 604k segments/s)
+    if (bf && a != b) ok = false;
+    if (akc < 0) akc = a, bkc = b;
+    if (a != akc || b != bkc) ok = false;
+    tiles += fh_cdiv(p.M, 64) * fh_cdiv(p.N, 64);
+  }
+  if (!ok) {
+    for (int i = 0; i < n; ++i) {
+      int e = launch_gemm(ps[i], dtype, st);
+      if (e) return e;
+    }
+    return FHVAE_OK;
+  }
+  GemmGroup g = {};
+  g.n = n;
+  unsigned gx = 1, gy = 1;
+  for (int i = 0; i < n; ++i) {
+    GemmParams p = ps[i];
+    if (p.splitk == 0) {
+      // enough K slices that the group as a whole offers ~3 workgroups per CU (long contractions are bandwidth-bound:
+      // they want the occupancy; short ones are latency-bound: they want the parallelism)
+      const int64_t panels = fh_cdiv(p.seg[0].K + p.seg[1].K, 32 * epc);
+      int64_t sk = panels < 4 ? 1 : fh_cdiv(768, tiles);
+      if (sk > panels / 2) sk = panels / 2;
+      if (sk < 1) sk = 1;
+      if (sk > 128) sk = 128;
+      p.splitk = (int)sk;
+      if (p.splitk > 1) p.mode = 2;
+    }
+    if (p.splitk < 1) p.splitk = 1;
+    g.p[i] = p;
+    g.zbase[i + 1] = g.zbase[i] + p.splitk;
+    gx = gx > (unsigned)fh_cdiv(p.N, 64) ? gx : (unsigned)fh_cdiv(p.N, 64);
+    gy = gy > (unsigned)fh_cdiv(p.M, 64) ? gy : (unsigned)fh_cdiv(p.M, 64);
+  }
+  dim3 grid(gx, gy, (unsigned)g.zbase[n]);
+  if (bf) {
+    if (akc)
+      hipLaunchKernelGGL((gemm_group_kernel<u16, 64, 64, 2, 2, 32, true, true>), grid, dim3(kThreads), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_group_kernel<u16, 64, 64, 2, 2, 32, false, false>), grid, dim3(kThreads), 0, st, g);
+  } else if (akc && bkc)
+    hipLaunchKernelGGL((gemm_group_kernel<float, 64, 64, 2, 2, 32, true, true>), grid, dim3(kThreads), 0, st, g);
+  else if (!akc && !bkc)
+    hipLaunchKernelGGL((gemm_group_kernel<float, 64, 64, 2, 2, 32, false, false>), grid, dim3(kThreads), 0, st, g);
+  else if (akc)
+    hipLaunchKernelGGL((gemm_group_kernel<float, 64, 64, 2, 2, 32, true, false>), grid, dim3(kThreads), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_group_kernel<float, 64, 64, 2, 2, 32, false, true>), grid, dim3(kThreads), 0, st, g);
   return fh_launch_status();
 }
 
@@ -429,9 +527,24 @@ extern "C" int fhvae_gauss_head_reparam_fwd(const void* h, int64_t ldh, const vo
   FH_CHECK_PTR(mu);
   FH_CHECK_PTR(logvar);
   if (eps && !sample) return FHVAE_ERR_NULL;
-  int e = fhvae_linear_fwd(h, ldh, w_mu, K, b_mu, mu, D, nullptr, M, K, D, 0, dtype, stream);
-  if (e) return e;
-  e = fhvae_linear_fwd(h, ldh, w_lv, K, b_lv, logvar, D, nullptr, M, K, D, 0, dtype, stream);
+  FH_CHECK_POS(M);
+  FH_CHECK_POS(K);
+  FH_CHECK_POS(D);
+  FH_CHECK_I32(M);
+  FH_CHECK_I32(K);
+  FH_CHECK_I32(D);
+  if (dtype != FHVAE_F32 && dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
+  GemmParams ps[2] = {};
+  for (int i = 0; i < 2; ++i) {  // mu and logvar share the operand h: one grouped launch
+    ps[i].seg[0] = Seg{h, ldh, 1, i == 0 ? w_mu : w_lv, K, 1, (int)K, 0};
+    ps[i].M = (int)M;
+    ps[i].N = (int)D;
+    ps[i].C = i == 0 ? mu : logvar;
+    ps[i].ldc = D;
+    ps[i].bias = i == 0 ? b_mu : b_lv;
+    ps[i].splitk = 1;
+  }
+  int e = launch_gemm_group(ps, 2, dtype, (hipStream_t)stream);
   if (e) return e;
   if (eps) {
     int64_t n = M * D;

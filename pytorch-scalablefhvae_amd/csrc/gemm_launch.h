@@ -21,6 +21,14 @@ struct GemmParams {
 };
 
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t st);
+constexpr int kMaxGroup = 4;
+struct GemmGroup {
+  int n;
+  int zbase[kMaxGroup + 1];  // problem i owns blockIdx.z in [zbase[i], zbase[i+1]) = its K slices
+  GemmParams p[kMaxGroup];
+};
+// several independent problems in one launch where they share a shape class (else one launch each)
+int launch_gemm_group(const GemmParams* ps, int n, int dtype, hipStream_t st);
 int pick_splitk(int64_t M, int64_t N, int64_t K);
 // split == 0: db and db2 both receive all N column sums; split > 0: columns < split -> db, the others -> db2
 int launch_colsum(const void* g, int dtype, int64_t ldg, float* db, float* db2, int64_t M, int64_t N, hipStream_t st,

@@ -598,9 +598,11 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
   const int64_t K0 = I + Ic, G = 4 * H;
   const T* dg = (const T*)bd->dgates;
   const T* hs = (const T*)d->hs;
-  auto wgrad = [&](const void* a, int64_t lda, const void* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc,
-                   int64_t Ncols, int dtype) -> int {
-    // c[G, Ncols] += a[Kc, G]^T . b[Kc, Ncols]
+  // c[G, Ncols] += a[Kc, G]^T . b[Kc, Ncols]; the operand-dtype contractions of the whole net go out as ONE grouped launch
+  // (at small batches each is a latency-bound launch of a few workgroups)
+  GemmParams grp[2 * FHVAE_MAX_LAYERS];
+  int ng = 0;
+  auto wgrad = [&](const void* a, int64_t lda, const void* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc, int64_t Ncols) {
     GemmParams p = {};
     p.seg[0] = Seg{a, lda, 0, b, ldb, 0, (int)Kc, 0};
     p.M = (int)G;
@@ -609,27 +611,27 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
     p.ldc = ldc;
     p.splitk = 0;  // auto (atomics when split)
     p.mode = 1;
-    return launch_gemm(p, dtype, st);
+    return p;
+  };
+  auto flush = [&]() -> int {
+    int e = FHVAE_OK;
+    for (int i = 0; i < ng && !e; i += kMaxGroup) e = launch_gemm_group(grp + i, ng - i < kMaxGroup ? ng - i : kMaxGroup, d->dtype, st);
+    ng = 0;
+    return e;
   };
   for (int l = 0; l < L; ++l) {
     const T* dgl = dg + (int64_t)l * T_ * B * G;
     const T* hl = hs + (int64_t)l * T_ * B * H;
     int e;
-    if (bd->dw_hh[l] && T_ > 1) {
-      e = wgrad(dgl + B * G, G, hl, H, (T_ - 1) * B, bd->dw_hh[l], H, H, d->dtype);
-      if (e) return e;
-    }
+    if (bd->dw_hh[l] && T_ > 1) grp[ng++] = wgrad(dgl + B * G, G, hl, H, (T_ - 1) * B, bd->dw_hh[l], H, H);
     if (bd->dw_ih[l]) {
       if (l > 0) {
-        e = wgrad(dgl, G, hs + (int64_t)(l - 1) * T_ * B * H, H, T_ * B, bd->dw_ih[l], H, H, d->dtype);
-        if (e) return e;
+        grp[ng++] = wgrad(dgl, G, hs + (int64_t)(l - 1) * T_ * B * H, H, T_ * B, bd->dw_ih[l], H, H);
       } else {
-        if (I > 0) {
-          e = wgrad(dgl, G, op.x, I, T_ * B, bd->dw_ih[0], K0, I, d->dtype);
-          if (e) return e;
-        }
-        if (Ic > 0) {
-          e = wgrad(bd->dgsum, G, d->xc, Ic, B, bd->dw_ih[0] + I, K0, Ic, FHVAE_F32);
+        if (I > 0) grp[ng++] = wgrad(dgl, G, op.x, I, T_ * B, bd->dw_ih[0], K0, I);
+        if (Ic > 0) {  // the time-constant input's part: f32 running sum over t of dg (B rows)
+          GemmParams p = wgrad(bd->dgsum, G, d->xc, Ic, B, bd->dw_ih[0] + I, K0, Ic);
+          e = launch_gemm(p, FHVAE_F32, st);
           if (e) return e;
         }
       }
@@ -639,7 +641,7 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
       if (e) return e;
     }
   }
-  return FHVAE_OK;
+  return flush();
 }
 
 // d_xc[B,Ic] = dgsum[B,4H] . W_ih0[:, I:]   (f32 master weight as KM operand: B(n, k) = W[k*K0 + I + n])
