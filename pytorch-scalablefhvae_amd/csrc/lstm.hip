@@ -332,7 +332,7 @@ static int check_desc(const fhvae_lstm_desc* d) {
 
 // layout of the bf16 workspace (element offsets, every block a multiple of 8 elements)
 struct LpLayout {
-  int64_t x, xc, w_ih[FHVAE_MAX_LAYERS], w_hh[FHVAE_MAX_LAYERS], w_ih_t[FHVAE_MAX_LAYERS], w_hh_t[FHVAE_MAX_LAYERS], total;
+  int64_t x, xc, w_ih[FHVAE_MAX_LAYERS], w_hh[FHVAE_MAX_LAYERS], w_ih_t[FHVAE_MAX_LAYERS], w_hh_t[FHVAE_MAX_LAYERS], xch, total;
 };
 static LpLayout lp_layout(const fhvae_lstm_desc* d) {
   LpLayout o;
@@ -351,6 +351,7 @@ static LpLayout lp_layout(const fhvae_lstm_desc* d) {
     o.w_ih_t[l] = take(l == 0 ? 0 : 4 * d->H * kin);
     o.w_hh_t[l] = take(4 * d->H * d->H);
   }
+  o.xch = take(2 * (int64_t)d->L * d->B * 4 * d->H);  // the persistent kernels' exchange buffer (lstm_cluster.hip)
   o.total = n;
   return o;
 }
@@ -446,6 +447,7 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     if (cluster) {  // persistent form: the whole recurrence in one launch (lstm_cluster.hip)
       ClusterWeights cw = {};
       for (int l = 0; l < L; ++l) cw.w_ih[l] = op.w_ih[l], cw.w_hh[l] = op.w_hh[l], cw.w_ih_t[l] = op.w_ih_t[l], cw.w_hh_t[l] = op.w_hh_t[l];
+      cw.xch = (u16*)d->lp + lp_layout(d).xch;
       cw.x_fold = fold ? (const u16*)op.x : nullptr;
       return cluster_fwd(d, cw, st);
     }
@@ -529,6 +531,7 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     if (cluster_eligible(d)) {  // the forward on this workspace took the persistent form too (same predicate)
       ClusterWeights cw = {};
       for (int l = 0; l < L; ++l) cw.w_ih[l] = op.w_ih[l], cw.w_hh[l] = op.w_hh[l], cw.w_ih_t[l] = op.w_ih_t[l], cw.w_hh_t[l] = op.w_hh_t[l];
+      cw.xch = (u16*)d->lp + lp_layout(d).xch;
       return cluster_bwd(bd, cw, st);
     }
   }

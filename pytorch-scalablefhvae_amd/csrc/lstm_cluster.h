@@ -20,6 +20,7 @@ struct ClusterWeights {  // bf16 operand copies in the workspace
   const u16* w_hh[FHVAE_MAX_LAYERS];    // [4H, H]
   const u16* w_ih_t[FHVAE_MAX_LAYERS];  // [H, 4H]   (l >= 1)
   const u16* w_hh_t[FHVAE_MAX_LAYERS];  // [H, 4H]
+  u16* xch;                             // exchange buffer: 2 * L * B * 4H bf16 (lstm_cluster.hip, xch_off)
   const u16* x_fold;                    // (T,B,I) bf16 when the forward kernels do the layer-0 input projection themselves
 };
 

@@ -127,6 +127,18 @@ __device__ __forceinline__ void glds_wave_panel(char* lds, const u16* base, int6
                                      (void __attribute__((address_space(3)))*)(lds + j * 1024), 16, 0, kSc1);
   }
 }
+// The EXCHANGE buffer of the contraction-split kernels.  What the members hand each other (h forward, dg backward) is ALSO
+// written in a blocked layout [parity][layer][k-step (32 contraction elements)][batch row][32] bf16, next to the row-major
+// tensors the later consumers read: an MFMA operand fragment (16 rows x 32 k) is then 1 KB of CONTIGUOUS memory instead of
+// 16 pieces of 64 B at the row stride -- measured (tools/exp/l2_read.hip, 16 readers per block, sc1 loads, one 64-KB burst
+// per CU) 57-74 GB/s per CU against 31 GB/s.  (The rows-form kernels stage 128-byte row segments and stream 512 KB per CU
+// and step: they sit at the ~10 TB/s aggregate L2 rate in either layout, 433 us against 398 with the extra stores.)
+// Two parities: step s writes parity s&1 and reads (s-1)&1; a member enters step s only after every member has finished its
+// reads of step s-2's parity.
+__device__ __forceinline__ int64_t xch_off(int par, int l, int L, int KS, int ks, int64_t B, int64_t row) {
+  return ((((int64_t)par * L + l) * KS + ks) * B + row) * 32;
+}
+
 // wait until at most `younger` panels (4 DMA instructions each) issued after the needed one are still in flight
 __device__ __forceinline__ void wait_panels(int younger) {
   if (younger >= 2)
@@ -177,6 +189,7 @@ struct ClFwd {
   u16* gates;  // (L,T,B,4H)
   float* hs_top_f32;  // optional (T,B,H)
   float* hn;          // optional (B, L*H)
+  u16* xch;  // exchange buffer (blocked copy of h; contraction-split form), see xch_off
   unsigned* sync;
   unsigned long long* tlog;  // optional phase clock log of cluster 0 / member 0 (tools/prof_cluster.py)
 };
@@ -489,6 +502,7 @@ struct ClBwd {
   float* dgsum;          // (B,4H) out: sum over t of layer 0's dg, or NULL
   float* db_ih[2];       // [4H] bias gradients (accumulated with atomics: += sum over t and rows of dg^l), may be NULL
   float* db_hh[2];
+  u16* xch;  // exchange buffer (blocked copy of dg; contraction-split form)
   unsigned* sync;
   unsigned long long* tlog;
 };
@@ -804,7 +818,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
     }
   };
   load_x(0);
-  const __amdgpu_buffer_rsrc_t hs_rs = make_rsrc(p.hs);
+  const __amdgpu_buffer_rsrc_t hs_rs = make_rsrc(p.xch);
   unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
   __syncthreads();  // weights have landed
 
@@ -828,9 +842,9 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
     for (int l = 0; l < L; ++l) {
       const int tau = s - l - 1;
       if (tau < 0 || tau >= T) continue;
-      const int64_t base = ((((int64_t)l * T + tau) * B + rowc) * H + (kp * KPW * 4 + q) * 8) * 2;
+      const int64_t base = (xch_off((s - 1) & 1, l, L, KS, kp * KPW, B, rowc) + q * 8) * 2;
 #pragma unroll
-      for (int j = 0; j < KPW; ++j) a[l][j] = load_sc1(hs_rs, base + j * 64);
+      for (int j = 0; j < KPW; ++j) a[l][j] = load_sc1(hs_rs, base + j * (B * 64));
     }
     f32x4 acc[L][4];
 #pragma unroll
@@ -902,7 +916,11 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
       creg = c;
 #pragma unroll
       for (int g = 0; g < 4; ++g) gpk[g] = pack4(gv[g]);
-      if (row < rend) *(uint2*)(p.hs + (((int64_t)kp * T + t) * B + row) * H + uq) = pack4(hreg);
+      if (row < rend) {
+        const uint2 hp = pack4(hreg);
+        *(uint2*)(p.xch + xch_off(s & 1, kp, L, KS, uq >> 5, B, row) + (uq & 31)) = hp;  // what the members wait for
+        *(uint2*)(p.hs + (((int64_t)kp * T + t) * B + row) * H + uq) = hp;
+      }
     }
     CL_TLOG(s * 8 + 3);
     if (s + 1 < nsteps) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));  // (its barrier also frees Part)
@@ -965,7 +983,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
   auto pack4 = [](const f32x4& v) -> uint2 {
     return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
   };
-  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(p.dg);
+  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(p.xch);
   unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
   __syncthreads();
 
@@ -998,9 +1016,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
     for (int l = 0; l < L; ++l) {
       const int tau = T - s + (L - 1 - l);
       if (s == 0 || tau < 0 || tau > T - 1) continue;
-      const int64_t base = ((((int64_t)l * T + tau) * B + rowc) * G + (kp * KPW * 4 + q) * 8) * 2;
+      const int64_t base = (xch_off((s - 1) & 1, l, L, KS, kp * KPW, B, rowc) + q * 8) * 2;
 #pragma unroll
-      for (int j = 0; j < KPW; ++j) a[l][j] = load_sc1(dg_rs, base + j * 64);
+      for (int j = 0; j < KPW; ++j) a[l][j] = load_sc1(dg_rs, base + j * (B * 64));
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -1052,7 +1070,11 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
       if (row < rend) {
         u16* go = p.dg + (((int64_t)kp * T + t) * B + row) * G + uq;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = pack4(dp[g]);
+        for (int g = 0; g < 4; ++g) {
+          const uint2 v = pack4(dp[g]);
+          *(uint2*)(p.xch + xch_off(s & 1, kp, L, KS, (g * H + uq) >> 5, B, row) + (uq & 31)) = v;
+          *(uint2*)(go + g * H) = v;
+        }
       }
     }
     CL_TLOG(s * 8 + 3);
@@ -1185,6 +1207,7 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     p.hs_top_f32 = d->hs_top_f32;
     p.hn = d->hn;
     p.sync = (unsigned*)d->lp;
+    p.xch = w.xch;
     p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
     p.seq = (int)(row0 / chunk);
     double fl = 0;
@@ -1272,6 +1295,7 @@ int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStrea
     p.dgsum = d->Ic > 0 ? bd->dgsum : nullptr;
     for (int l = 0; l < L; ++l) p.db_ih[l] = bd->db_ih[l], p.db_hh[l] = bd->db_hh[l];
     p.sync = (unsigned*)d->lp;
+    p.xch = w.xch;
     p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
     double fl = 0;
     for (int l = 0; l < L; ++l) fl += 2.0 * nrows * H * ((l < L - 1 ? d->T * 4.0 * H : 0) + (d->T - 1) * 4.0 * H);
