@@ -992,7 +992,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
     CL_TLOG(s * 8 + 0);
     const int t = T - 1 - (s - (L - 1 - kp));  // the time layer kp handles at this step
     const bool act = epi && t >= 0 && t < T;
-    uint2 gk[4];
+    uint2 gk[4], dpk[4];
     f32x4 cprev, ext;
     if (act) {
       const int64_t lt = (int64_t)kp * T + t;
@@ -1068,18 +1068,21 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
         for (int g = 0; g < 4; ++g) dgs[g] += dp[g];
       }
       if (row < rend) {
-        u16* go = p.dg + (((int64_t)kp * T + t) * B + row) * G + uq;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const uint2 v = pack4(dp[g]);
-          *(uint2*)(p.xch + xch_off(s & 1, kp, L, KS, (g * H + uq) >> 5, B, row) + (uq & 31)) = v;
-          *(uint2*)(go + g * H) = v;
+          dpk[g] = pack4(dp[g]);
+          *(uint2*)(p.xch + xch_off(s & 1, kp, L, KS, (g * H + uq) >> 5, B, row) + (uq & 31)) = dpk[g];  // what the members wait for
         }
       }
     }
     CL_TLOG(s * 8 + 3);
     if (s + 1 < nsteps) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));
     CL_TLOG(s * 8 + 4);
+    if (act && row < rend) {  // the row-major copy the weight-gradient contractions read: after the publish
+      u16* go = p.dg + (((int64_t)kp * T + t) * B + row) * G + uq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = dpk[g];
+    }
   }
   if (p.dgsum && kp == 0 && row < rend) {
 #pragma unroll
