@@ -987,24 +987,34 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
   unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
   __syncthreads();
 
+  uint2 gkn[4];
+  f32x4 cprevn, extn, ccurn;
+  auto load_epi = [&](int sn) {
+    const int t = T - 1 - (sn - (L - 1 - kp));
+    if (!(epi && t >= 0 && t < T)) return;
+    const int64_t lt = (int64_t)kp * T + t;
+    const u16* gp = p.gates + (lt * B + rowc) * G + uq;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gkn[g] = *(const uint2*)(gp + g * H);
+    if (t == T - 1) ccurn = *(const f32x4*)(p.cs + (lt * B + rowc) * H + uq);
+    cprevn = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + rowc) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    extn = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kp == L - 1 && p.d_hs_top) extn = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + rowc) * H + uq);
+    if (t == T - 1 && p.d_hn) extn += *(const f32x4*)(p.d_hn + rowc * (L * H) + kp * H + uq);
+  };
+  load_epi(0);
   const int nsteps = T + L - 1;
   for (int s = 0; s < nsteps; ++s) {
     CL_TLOG(s * 8 + 0);
     const int t = T - 1 - (s - (L - 1 - kp));  // the time layer kp handles at this step
     const bool act = epi && t >= 0 && t < T;
+    // the saved activations / cell state / upstream gradient of this step were fetched during step s-1 (they come from
+    // HBM and loads return in order: fetched here they would sit in front of the flag poll)
     uint2 gk[4], dpk[4];
-    f32x4 cprev, ext;
-    if (act) {
-      const int64_t lt = (int64_t)kp * T + t;
-      const u16* gp = p.gates + (lt * B + rowc) * G + uq;
+    f32x4 cprev = cprevn, ext = extn;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) gk[g] = *(const uint2*)(gp + g * H);
-      if (t == T - 1) ccur = *(const f32x4*)(p.cs + (lt * B + rowc) * H + uq);
-      cprev = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + rowc) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
-      ext = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kp == L - 1 && p.d_hs_top) ext = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + rowc) * H + uq);
-      if (t == T - 1 && p.d_hn) ext += *(const f32x4*)(p.d_hn + rowc * (L * H) + kp * H + uq);
-    }
+    for (int g = 0; g < 4; ++g) gk[g] = gkn[g];
+    if (act && t == T - 1) ccur = ccurn;
     if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
     CL_TLOG(s * 8 + 1);
 
@@ -1041,6 +1051,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) *(f32x4*)(Part + (wave * L + l) * 1024 + lane * 16) = acc[l];
+    if (s + 1 < nsteps) load_epi(s + 1);
     __syncthreads();
     CL_TLOG(s * 8 + 2);
     if (act) {
