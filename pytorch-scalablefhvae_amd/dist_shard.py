@@ -236,8 +236,9 @@ class DistributedFHVAE:
         import hip_binding as hb
 
         # The persistent LSTM kernels need all 256 CUs co-resident: a collective kernel spinning on its peers next to
-        # them would hold some of those CUs for as long as the slowest rank takes.  With that schedule the gradients are
-        # reduced after the backward instead, in one collective over the whole arena (_reduce_gradients).
+        # them would hold some of those CUs for as long as the slowest rank takes.  With that schedule the buckets of the
+        # first two nets are reduced under the LAST net's weight-gradient contractions instead (_on_lstm_rec_done), where
+        # no persistent kernel follows before the optimizer.
         if not self.overlap or not sinks or sinks[0] is None or hb.LAST_LSTM_FORM["form"] != 0:
             return
         g = self._bucket_of_ptr.get(sinks[0].data_ptr())
@@ -246,6 +247,24 @@ class DistributedFHVAE:
         b, e = self._buckets[g]
         h = self.sh.all_reduce_(self.opt_nets.g_arena.flat[b:e], async_op=True)
         self._pending[g] = h  # None when the transport was synchronous (staged gloo)
+
+    def _on_lstm_rec_done(self, sinks):
+        """Fired by hip_binding between a net's backward recurrence and its parameter-gradient contractions.  Persistent
+        schedule only: once the LAST net's recurrence is enqueued, the finished buckets of the earlier nets (contiguous in
+        the arena) go out as one async all-reduce that overlaps this net's weight gradients and its head's backward."""
+        import hip_binding as hb
+
+        if not self.overlap or not sinks or sinks[0] is None or hb.LAST_LSTM_FORM["form"] == 0:
+            return
+        g = self._bucket_of_ptr.get(sinks[0].data_ptr())
+        last = len(self._buckets) - 1
+        if g != last or self._pending or last < 1:
+            return
+        b, e = self._buckets[0][0], self._buckets[last - 1][1]
+        if e > b:
+            h = self.sh.all_reduce_(self.opt_nets.g_arena.flat[b:e], async_op=True)
+            for k in range(last):
+                self._pending[k] = h if k == 0 else None
 
     def _reduce_gradients(self):
         flat = self.opt_nets.flat_grad()
@@ -272,10 +291,12 @@ class DistributedFHVAE:
         out = self.model(x, idx, self.sh.S, nsegs)
         loss = loss_function(out[0], out[1], alpha)
         hb.LSTM_BWD_DONE_HOOK["fn"] = self._on_lstm_bwd_done
+        hb.LSTM_BWD_REC_HOOK["fn"] = self._on_lstm_rec_done
         try:
             loss.backward()
         finally:
             hb.LSTM_BWD_DONE_HOOK["fn"] = None
+            hb.LSTM_BWD_REC_HOOK["fn"] = None
         self._reduce_gradients()  # C1: three bucket all-reduces, two of them already in flight under the backward
         self.opt_nets.step()
         self.opt_table.step()

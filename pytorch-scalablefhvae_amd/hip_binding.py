@@ -139,6 +139,7 @@ _SIDE = {"stream": None, "pending": False, "keep": [], "enabled": False}
 
 #: optional callback(params_tuple) fired at the end of every _LstmSeq.backward: the data-parallel wrapper uses it to
 #: start the all-reduce of a net's gradient bucket while the next net's backward recurrence still runs
+LSTM_BWD_REC_HOOK = {"fn": None}  # fn(sinks): fired between a net's backward recurrence and its parameter gradients
 LSTM_BWD_DONE_HOOK = {"fn": None}
 
 
@@ -528,6 +529,16 @@ class _LstmSeq(torch.autograd.Function):
                     _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
             _SIDE["pending"] = True
             _SIDE["keep"].append((x_tm, xc, hs, cs, gates, lp, dgates, dgsum, dc, d_hs_top, d_hn, params))
+        elif LSTM_BWD_REC_HOOK["fn"] is not None:
+            # recurrence, hook (the distributed runner starts collectives that may overlap the weight-gradient
+            # contractions but must not overlap a persistent recurrence kernel), then the parameter gradients
+            bd.phase = 1
+            with _Timed("fhvae_lstm_seq_bwd"):
+                _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
+            LSTM_BWD_REC_HOOK["fn"](ctx.sinks)
+            bd.phase = 2
+            with _Timed("fhvae_lstm_seq_bwd(param grads)"):
+                _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
         else:
             bd.phase = 0
             with _Timed("fhvae_lstm_seq_bwd"):
