@@ -77,3 +77,37 @@ def test_cluster_matches_step_kernels(hb, B, T, I, Ic, H, L):
     assert (a[0].cpu() - ref).abs().max().item() < 3e-2 * ref.abs().max().item()
     hn_cat = torch.cat([hn[l] for l in range(L)], -1)
     assert (a[1].cpu() - hn_cat).abs().max().item() < 3e-2 * hn_cat.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,L,form", [(256, 256, 2, 2), (512, 256, 2, 2), (1024, 256, 2, 1), (2048, 256, 2, 1), (4096, 128, 2, 1),
+                                        (256, 64, 2, 0), (256, 512, 2, 0), (256, 256, 3, 0)])
+def test_schedule_choice_and_repeatability(hb, B, H, L, form):
+    """fhvae_lstm_form reports the schedule; the forward of every schedule is bit-repeatable (the persistent kernels
+    exchange data between workgroups inside a launch: a stale or torn read would show up as run-to-run differences)."""
+    torch.manual_seed(3)
+    T, I = 6, 80
+    lstm = torch.nn.LSTM(I, H, L)
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    params = [getattr(lstm, n).detach().cuda() for n in names]
+    x = torch.randn(T, B, I).cuda()
+    outs = []
+    for _ in range(4):
+        hs, hn = hb.lstm_seq(x, None, T, params, hb.BF16)
+        outs.append((hs.clone(), hn.clone()))
+    torch.cuda.synchronize()
+    assert hb.LAST_LSTM_FORM["form"] == form
+    assert hb.lstm_sync_status() == 0
+    for hs, hn in outs[1:]:
+        assert torch.equal(hs, outs[0][0]) and torch.equal(hn, outs[0][1])
+
+
+def test_no_cluster_env_forces_step_kernels(hb):
+    os.environ["FHVAE_NO_CLUSTER"] = "1"
+    try:
+        lstm = torch.nn.LSTM(80, 256, 2)
+        names = [n + "_l%d" % l for l in range(2) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        params = [getattr(lstm, n).detach().cuda() for n in names]
+        hb.lstm_seq(torch.randn(4, 256, 80).cuda(), None, 4, params, hb.BF16)
+        assert hb.LAST_LSTM_FORM["form"] == 0
+    finally:
+        os.environ.pop("FHVAE_NO_CLUSTER", None)
