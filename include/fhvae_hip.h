@@ -92,6 +92,14 @@ int fhvae_gauss_head_bwd(const float* h, int64_t ldh, const float* w_mu, const f
                          const float* eps, const float* logvar, float* g_ws, float* dh, int64_t lddh,
                          float* dw_mu, float* dw_lv, float* db_mu, float* db_lv, int64_t M, int64_t K,
                          int64_t D, void* stream);
+/* The same with bf16 MFMA operands (compute_dtype = bf16): h_lp [M,K] bf16, w_mu_t_lp / w_lv_t_lp [K,D] bf16 = the
+ * TRANSPOSED weights (fhvae_cast_bf16's dst_t), g_lp [M,2D] bf16 workspace.  Accumulation, dh and the parameter
+ * gradients stay f32. */
+int fhvae_gauss_head_bwd_lp(const void* h_lp, int64_t ldh, const void* w_mu_t_lp, const void* w_lv_t_lp,
+                            const float* d_mu, const float* d_logvar, const float* d_sample,
+                            const float* eps, const float* logvar, void* g_lp, float* dh, int64_t lddh,
+                            float* dw_mu, float* dw_lv, float* db_mu, float* db_lv, int64_t M, int64_t K,
+                            int64_t D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-layer LSTM over a whole segment (K1), step-fused cells: one launch per wavefront step

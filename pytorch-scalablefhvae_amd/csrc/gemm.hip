@@ -415,16 +415,23 @@ __global__ void reparam_bwd_kernel(const float* __restrict__ d_mu, const float* 
 
 // g[M, 2D] = [g_mu | g_lv]: the two linear layers' upstream gradients side by side, so that one contraction / one
 // column sum serves both
+template <typename TO>
 __global__ void reparam_bwd_cat_kernel(const float* __restrict__ d_mu, const float* __restrict__ d_lv,
                                        const float* __restrict__ d_s, const float* __restrict__ eps,
-                                       const float* __restrict__ lv, float* __restrict__ g, int64_t n, int D) {
+                                       const float* __restrict__ lv, TO* __restrict__ g, int64_t n, int D) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t m = i / D, c = i - m * D;
   float ds = d_s ? d_s[i] : 0.f;
   float e = (d_s && eps) ? ds * eps[i] * 0.5f * expf(0.5f * lv[i]) : 0.f;
-  g[m * 2 * D + c] = (d_mu ? d_mu[i] : 0.f) + ds;
-  g[m * 2 * D + D + c] = (d_lv ? d_lv[i] : 0.f) + e;
+  const float gm = (d_mu ? d_mu[i] : 0.f) + ds, gl = (d_lv ? d_lv[i] : 0.f) + e;
+  if constexpr (sizeof(TO) == 4) {
+    g[m * 2 * D + c] = gm;
+    g[m * 2 * D + D + c] = gl;
+  } else {
+    g[m * 2 * D + c] = f2bf(gm);
+    g[m * 2 * D + D + c] = f2bf(gl);
+  }
 }
 
 }  // namespace fh
@@ -580,7 +587,7 @@ extern "C" int fhvae_gauss_head_bwd(const float* h, int64_t ldh, const float* w_
   if (d_sample && (!eps || !logvar)) return FHVAE_ERR_NULL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = M * D;
-  hipLaunchKernelGGL(reparam_bwd_cat_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, d_mu, d_logvar, d_sample, eps,
+  hipLaunchKernelGGL(reparam_bwd_cat_kernel<float>, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, d_mu, d_logvar, d_sample, eps,
                      logvar, g_ws, n, (int)D);
   int e = fh_launch_status();
   if (e) return e;
@@ -616,5 +623,61 @@ extern "C" int fhvae_gauss_head_bwd(const float* h, int64_t ldh, const float* w_
     if (e) return e;
   }
   if (db_mu || db_lv) return launch_colsum(g_ws, FHVAE_F32, 2 * D, db_mu, db_lv, M, 2 * D, st, D);
+  return FHVAE_OK;
+}
+
+// bf16-operand form of the above (compute_dtype = bf16): h_lp [M,K] bf16 (the LSTM's own hidden-state buffer), the transposed
+// bf16 weights w_*_t_lp [K,D] (fhvae_cast_bf16), g_lp [M,2D] bf16 workspace; accumulation, dh and the parameter gradients f32
+extern "C" int fhvae_gauss_head_bwd_lp(const void* h_lp, int64_t ldh, const void* w_mu_t_lp, const void* w_lv_t_lp,
+                                       const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
+                                       const float* logvar, void* g_lp, float* dh, int64_t lddh, float* dw_mu, float* dw_lv,
+                                       float* db_mu, float* db_lv, int64_t M, int64_t K, int64_t D, void* stream) {
+  FH_CHECK_PTR(g_lp);
+  FH_CHECK_POS(M);
+  FH_CHECK_POS(K);
+  FH_CHECK_POS(D);
+  FH_CHECK_I32(M);
+  FH_CHECK_I32(K);
+  FH_CHECK_I32(2 * D);
+  if (d_sample && (!eps || !logvar)) return FHVAE_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = M * D;
+  u16* g = (u16*)g_lp;
+  hipLaunchKernelGGL(reparam_bwd_cat_kernel<u16>, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, d_mu, d_logvar, d_sample, eps,
+                     logvar, g, n, (int)D);
+  int e = fh_launch_status();
+  if (e) return e;
+  if (dh) {  // dh[M,K] = g_mu . W_mu + g_lv . W_lv with the transposed weight copies as KC operands
+    FH_CHECK_PTR(w_mu_t_lp);
+    FH_CHECK_PTR(w_lv_t_lp);
+    GemmParams p = {};
+    p.seg[0] = Seg{g, 2 * D, 1, w_mu_t_lp, D, 1, (int)D};
+    p.seg[1] = Seg{g + D, 2 * D, 1, w_lv_t_lp, D, 1, (int)D};
+    p.M = (int)M;
+    p.N = (int)K;
+    p.C = dh;
+    p.ldc = lddh;
+    p.splitk = 1;
+    e = launch_gemm(p, FHVAE_BF16, st);
+    if (e) return e;
+  }
+  if (dw_mu || dw_lv) {
+    FH_CHECK_PTR(h_lp);
+    FH_CHECK_PTR(dw_mu);
+    FH_CHECK_PTR(dw_lv);
+    GemmParams p = {};
+    p.seg[0] = Seg{g, 2 * D, 0, h_lp, ldh, 0, (int)M};
+    p.M = (int)(2 * D);
+    p.N = (int)K;
+    p.C = dw_mu;
+    p.C2 = dw_lv;
+    p.c_split = (int)D;
+    p.ldc = K;
+    p.mode = 1;
+    p.splitk = 0;
+    e = launch_gemm(p, FHVAE_BF16, st);
+    if (e) return e;
+  }
+  if (db_mu || db_lv) return launch_colsum(g, FHVAE_BF16, 2 * D, db_mu, db_lv, M, 2 * D, st, D);
   return FHVAE_OK;
 }

@@ -117,7 +117,9 @@ class FHVAE(FHVAEBase):
         z1_mu, z1_logvar, z1_sample = self.z1_gauss_layer(hn1, e1)
         hs_top, _ = self.pre_decoder(None, torch.cat([z1_sample, z2_sample], dim=-1), T, dt)
         H = hs_top.shape[-1]
-        x_mu, x_logvar, _ = self.dec_gauss_layer(hs_top.reshape(T * B, H), sample=False)  # (T*B, F) time-major
+        hs_lp = getattr(hs_top, "_fh_lp", None)  # bf16 mode: the top layer's h in bf16 = the per-frame head's operand
+        x_mu, x_logvar, _ = self.dec_gauss_layer(hs_top.reshape(T * B, H), sample=False,  # (T*B, F) time-major
+                                                 input_lp=hs_lp.reshape(T * B, H) if hs_lp is not None else None)
 
         layout = (B, T, F_, (F_, B * F_), (F_, B * F_))  # x_tm and x_mu/x_logvar are all time-major
         return self._tail(x_tm, layout, x_mu, x_logvar, (z1_mu, z1_logvar), (z2_mu, z2_logvar), mu2, mu2_table, mu_idx,

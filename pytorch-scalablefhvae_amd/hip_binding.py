@@ -80,6 +80,7 @@ SIGNATURES = {
                                                _vp]),
     "fhvae_gauss_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fhvae_gauss_head_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_gauss_head_bwd_lp": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_form": (C.c_int, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
@@ -386,8 +387,70 @@ class _GaussHead(torch.autograd.Function):
         return dh, dw_mu, db_mu, dw_lv, db_lv, None
 
 
-def gauss_head(h, w_mu, b_mu, w_lv, b_lv, eps):
-    mu, lv, smp = _GaussHead.apply(h, w_mu, b_mu, w_lv, b_lv, eps)
+class _GaussHeadLp(torch.autograd.Function):
+    """_GaussHead with bf16 MFMA operands: `h` (f32) only carries the gradient, the contraction reads `h_lp` (the same
+    values in bf16) and bf16 copies of the weights; outputs, gradients and accumulation are f32."""
+
+    @staticmethod
+    def forward(ctx, h, h_lp, w_mu, b_mu, w_lv, b_lv, eps):
+        _need_gpu(h, h_lp, w_mu, b_mu, w_lv, b_lv, eps)
+        lib = load_library()
+        ctx.set_materialize_grads(False)
+        ctx.sinks = tuple(_sink(t) for t in (w_mu, b_mu, w_lv, b_lv))
+        w_mu, b_mu, w_lv, b_lv = _f32c(w_mu), _f32c(b_mu), _f32c(w_lv), _f32c(b_lv)
+        M, K = h_lp.shape
+        D = w_mu.shape[0]
+        assert h_lp.dtype == torch.bfloat16 and h_lp.is_contiguous() and h.shape == h_lp.shape
+        dev = h_lp.device
+        wl = torch.empty(2, D, K, device=dev, dtype=torch.bfloat16)     # bf16 weights
+        wt = torch.empty(2, K, D, device=dev, dtype=torch.bfloat16)     # ... and their transposes (backward's KC operands)
+        for i, w in enumerate((w_mu, w_lv)):
+            _check(lib.fhvae_cast_bf16(_p(w), _p(wl[i]), _p(wt[i]), D, K, _stream()), "fhvae_cast_bf16")
+        mu = torch.empty(M, D, device=dev, dtype=torch.float32)
+        lv = torch.empty_like(mu)
+        eps = _f32c(eps) if eps is not None else None
+        smp = torch.empty_like(mu) if eps is not None else None
+        with _Timed("fhvae_gauss_head_reparam_fwd"):
+            _check(lib.fhvae_gauss_head_reparam_fwd(_p(h_lp), K, _p(wl[0]), _p(wl[1]), _p(b_mu), _p(b_lv), _p(eps), _p(mu), _p(lv),
+                                                    _p(smp), M, K, D, BF16, _stream()), "fhvae_gauss_head_reparam_fwd")
+        ctx.save_for_backward(h_lp, wt, eps, lv)
+        if smp is None:
+            smp = mu.new_zeros(())
+            ctx.mark_non_differentiable(smp)
+        return mu, lv, smp
+
+    @staticmethod
+    def backward(ctx, d_mu, d_lv, d_s):
+        lib = load_library()
+        h_lp, wt, eps, lv = ctx.saved_tensors
+        if eps is None:
+            d_s = None
+        M, D = lv.shape
+        K = h_lp.shape[1]
+        d_mu = _f32c(d_mu) if d_mu is not None else None
+        d_lv = _f32c(d_lv) if d_lv is not None else None
+        d_s = _f32c(d_s) if d_s is not None else None
+        need_dh = ctx.needs_input_grad[0]
+        sk = ctx.sinks
+        dev = h_lp.device
+        outs = [k if k is not None else torch.zeros(shape, device=dev, dtype=torch.float32)
+                for k, shape in zip(sk, ((D, K), (D,), (D, K), (D,)))]
+        g_lp = torch.empty(M, 2 * D, device=dev, dtype=torch.bfloat16)
+        dh = torch.empty(M, K, device=dev, dtype=torch.float32) if need_dh else None
+        with _Timed("fhvae_gauss_head_bwd"):
+            _check(lib.fhvae_gauss_head_bwd_lp(_p(h_lp), K, _p(wt[0]), _p(wt[1]), _p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), _p(g_lp),
+                                               _p(dh), K, _p(outs[0]), _p(outs[2]), _p(outs[1]), _p(outs[3]), M, K, D, _stream()),
+                   "fhvae_gauss_head_bwd_lp")
+        dw_mu, db_mu, dw_lv, db_lv = (None if k is not None else o for k, o in zip(sk, outs))
+        return dh, None, dw_mu, db_mu, dw_lv, db_lv, None
+
+
+def gauss_head(h, w_mu, b_mu, w_lv, b_lv, eps, h_lp=None):
+    """h_lp: optional bf16 copy of h -> the contractions run on bf16 MFMA operands (K and D multiples of 8)."""
+    if h_lp is not None and h.shape[1] % 8 == 0 and w_mu.shape[0] % 8 == 0:
+        mu, lv, smp = _GaussHeadLp.apply(h, h_lp, w_mu, b_mu, w_lv, b_lv, eps)
+    else:
+        mu, lv, smp = _GaussHead.apply(h, w_mu, b_mu, w_lv, b_lv, eps)
     return mu, lv, (smp if eps is not None else None)
 
 
@@ -487,7 +550,10 @@ class _LstmSeq(torch.autograd.Function):
         ctx.dims, ctx.dtype = dims, dtype
         ctx.x_lp = x_lp
         ctx.save_for_backward(x_tm, xc, hs, cs, gates, lp, *params)
-        return (hs_top if bf else hs[L - 1]), hn
+        out = hs_top if bf else hs[L - 1]
+        if bf:
+            out._fh_lp = hs[L - 1]  # the same values in bf16 (what the recurrence itself consumed): operand of a bf16 head
+        return out, hn
 
     @staticmethod
     def backward(ctx, d_hs_top, d_hn):

@@ -61,11 +61,12 @@ class GaussianLayer(nn.Module):
         self.mulayer = nn.Linear(input_size, dim)
         self.logvar_layer = nn.Linear(input_size, dim)
 
-    def forward(self, input_layer: torch.Tensor, eps=None, sample=True):
+    def forward(self, input_layer: torch.Tensor, eps=None, sample=True, input_lp=None):
+        """input_lp: optional bf16 copy of input_layer (compute_dtype='bf16' models): bf16 MFMA operands."""
         if sample and eps is None:
             eps = torch.randn(input_layer.shape[0], self.mulayer.out_features, device=input_layer.device)
         return hb.gauss_head(input_layer, self.mulayer.weight, self.mulayer.bias, self.logvar_layer.weight,
-                             self.logvar_layer.bias, eps if sample else None)
+                             self.logvar_layer.bias, eps if sample else None, h_lp=input_lp)
 
 
 class PreDecoder(nn.Module):
