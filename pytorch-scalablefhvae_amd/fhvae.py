@@ -52,10 +52,10 @@ class LSTMNet(nn.Module):
             raise ValueError("all layers of one LSTM net must share the hidden size (got %s)" % (hus,))
         self.lstm = LSTMParams(input_size, hus[0], len(hus))
 
-    def forward(self, x_tm, xc, T, dtype=hb.F32):
+    def forward(self, x_tm, xc, T, dtype=hb.F32, top=2):
         """x_tm (T,B,I) time-major or None; xc (B,Ic) constant-over-time extra input or None.
-        Returns (top-layer h_t (T,B,H), concat of final h of all layers (B, L*H))."""
-        return hb.lstm_seq(x_tm, xc, T, self.lstm.flat(), dtype)
+        Returns (top-layer h_t (T,B,H), concat of final h of all layers (B, L*H)).  `top`: hip_binding.lstm_seq."""
+        return hb.lstm_seq(x_tm, xc, T, self.lstm.flat(), dtype, top)
 
 
 class FHVAE(FHVAEBase):
@@ -111,11 +111,14 @@ class FHVAE(FHVAEBase):
 
         dt = hb.BF16 if self.compute_dtype == "bf16" else hb.F32
         x_tm = hb.to_time_major(x, with_bf16=dt == hb.BF16)  # (T,B,F): contiguous per-step tiles for the step-fused cells
-        _, hn2 = self.z2_pre_encoder(x_tm, None, T, dt)
+        # the encoders only use their final states; in bf16 mode the decoder's per-frame head reads the bf16 states, so the
+        # f32 copy of the per-step states is not written at all (top=0 / top=1)
+        _, hn2 = self.z2_pre_encoder(x_tm, None, T, dt, top=0)
         z2_mu, z2_logvar, z2_sample = self.z2_gauss_layer(hn2, e2)
-        _, hn1 = self.z1_pre_encoder(x_tm, z2_sample, T, dt)
+        _, hn1 = self.z1_pre_encoder(x_tm, z2_sample, T, dt, top=0)
         z1_mu, z1_logvar, z1_sample = self.z1_gauss_layer(hn1, e1)
-        hs_top, _ = self.pre_decoder(None, torch.cat([z1_sample, z2_sample], dim=-1), T, dt)
+        lp_head = dt == hb.BF16 and self.x_hus[-1] % 8 == 0 and F_ % 8 == 0  # (hip_binding.gauss_head's condition)
+        hs_top, _ = self.pre_decoder(None, torch.cat([z1_sample, z2_sample], dim=-1), T, dt, top=1 if lp_head else 2)
         H = hs_top.shape[-1]
         hs_lp = getattr(hs_top, "_fh_lp", None)  # bf16 mode: the top layer's h in bf16 = the per-frame head's operand
         x_mu, x_logvar, _ = self.dec_gauss_layer(hs_top.reshape(T * B, H), sample=False,  # (T*B, F) time-major

@@ -507,7 +507,9 @@ class _LstmSeq(torch.autograd.Function):
     dtype = F32 (exact-f32 MFMA) or BF16 (bf16 MFMA operands, f32 accumulate / cell state)."""
 
     @staticmethod
-    def forward(ctx, x_tm, xc, T, dtype, *params):
+    def forward(ctx, x_tm, xc, T, dtype, top, *params):
+        """top: 2 = f32 top-layer h_t is an output (default); 1 (bf16 only) = the returned f32 tensor only ROUTES the
+        gradient, its values are undefined and the data is its `_fh_lp` bf16 twin; 0 = no per-step output at all (only hn)."""
         lib = load_library()
         ctx.set_materialize_grads(False)  # encoders use only hn, the decoder only hs_top: the other gradient stays None
         _need_gpu(x_tm, xc, *params)
@@ -533,7 +535,9 @@ class _LstmSeq(torch.autograd.Function):
         gates = torch.empty(L, T, B, 4 * H, device=dev, dtype=hs.dtype)
         hn = torch.empty(B, L * H, **f32)
         pre = torch.empty((T if I > 0 else 1), B, 4 * H, **f32)
-        hs_top = torch.empty(T, B, H, **f32) if bf else None
+        if not bf:
+            top = 2
+        hs_top = torch.empty(T, B, H, **f32) if (bf and top != 0) else None
         d = LstmDesc()
         dims = (L, B, T, I, Ic, H)
         _fill_lstm_desc(d, dtype, dims, x_tm, xc, params, x_lp)
@@ -543,13 +547,17 @@ class _LstmSeq(torch.autograd.Function):
             LSTM_WORKSPACES.append(lp)
             del LSTM_WORKSPACES[:-16]
             d.lp = _p(lp)
-        d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.pre, d.lp = _p(hs), _p(cs), _p(gates), _p(hn), _p(hs_top), _p(pre), _p(lp)
+        d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.pre, d.lp = _p(hs), _p(cs), _p(gates), _p(hn), _p(hs_top if top == 2 else None), _p(pre), _p(lp)
         LAST_LSTM_FORM["form"] = int(lib.fhvae_lstm_form(C.byref(d)))
         with _Timed("fhvae_lstm_seq_fwd"):
             _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")
         ctx.dims, ctx.dtype = dims, dtype
         ctx.x_lp = x_lp
         ctx.save_for_backward(x_tm, xc, hs, cs, gates, lp, *params)
+        if top == 0:
+            out = hn.new_zeros(())  # placeholder: this net's per-step states are not an output
+            ctx.mark_non_differentiable(out)
+            return out, hn
         out = hs_top if bf else hs[L - 1]
         if bf:
             out._fh_lp = hs[L - 1]  # the same values in bf16 (what the recurrence itself consumed): operand of a bf16 head
@@ -564,7 +572,7 @@ class _LstmSeq(torch.autograd.Function):
         dev = hs.device
         f32 = dict(device=dev, dtype=torch.float32)
         if d_hs_top is None and d_hn is None:
-            return (None,) * (4 + 4 * L)
+            return (None,) * (5 + 4 * L)
         d_hs_top = _f32c(d_hs_top) if d_hs_top is not None else None
         d_hn = _f32c(d_hn) if d_hn is not None else None
         bd = LstmBwdDesc()
@@ -611,11 +619,13 @@ class _LstmSeq(torch.autograd.Function):
                 _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
         if LSTM_BWD_DONE_HOOK["fn"] is not None:
             LSTM_BWD_DONE_HOOK["fn"](ctx.sinks)
-        return (None, d_xc, None, None, *[None if sk is not None else g for g, sk in zip(grads, ctx.sinks)])
+        return (None, d_xc, None, None, None, *[None if sk is not None else g for g, sk in zip(grads, ctx.sinks)])
 
 
-def lstm_seq(x_tm, xc, T, params: Sequence[torch.Tensor], dtype: int = F32):
-    return _LstmSeq.apply(x_tm, xc, int(T), int(dtype), *params)
+def lstm_seq(x_tm, xc, T, params: Sequence[torch.Tensor], dtype: int = F32, top: int = 2):
+    """top (bf16 only; see _LstmSeq.forward): 2 = f32 top-layer states are written and returned; 1 = the returned f32
+    tensor carries the gradient only (values undefined, data in its `_fh_lp`); 0 = only the final states are wanted."""
+    return _LstmSeq.apply(x_tm, xc, int(T), int(dtype), int(top), *params)
 
 
 def raw_gather_rows(table, idx, idx_offset=0):
