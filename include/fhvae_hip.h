@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 1
+#define FHVAE_ABI_VERSION 2
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -162,6 +162,8 @@ typedef struct fhvae_lstm_bwd_desc {
   int32_t phase;  /* 0: everything; 1: the recurrence (dgates, dgsum, d_xc) only; 2: the weight/bias gradient
                      contractions only (reads what phase 1 left in dgates/dgsum) -- lets the host put phase 2 on a
                      second stream, under the next net's latency-bound recurrence */
+  float* ws_below; /* (T,B,H) f32 workspace, required when fhvae_lstm_form(&f) == 1 and L > 1: the persistent backward runs
+                      layer by layer and hands the from-above gradient dg^{l+1}.W_ih^{l+1} to the lower layer through it */
 } fhvae_lstm_bwd_desc;
 
 int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* d, void* stream);

@@ -29,6 +29,7 @@
 #include <cstring>
 
 #include "gemm_core.h"
+#include "gemm_launch.h"
 #include "trace.h"
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -498,6 +499,7 @@ struct ClBwd {
   const float* cs;       // (L,T,B,H)
   const float* d_hs_top; // (T,B,H) or NULL
   const float* d_hn;     // (B,L*H) or NULL
+  int hn_ld;             // row stride of d_hn (the layer kernel gets the slot of its layer pre-offset)
   u16* dg;               // (L,T,B,4H) out
   float* dgsum;          // (B,4H) out: sum over t of layer 0's dg, or NULL
   float* db_ih[2];       // [4H] bias gradients (accumulated with atomics: += sum over t and rows of dg^l), may be NULL
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
         cprev[l][tm] = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + row) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
         if (l == L - 1 && p.d_hs_top) e = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + row) * H + uq);
-        if (t == T - 1 && p.d_hn) e += *(const f32x4*)(p.d_hn + row * (L * H) + l * H + uq);
+        if (t == T - 1 && p.d_hn) e += *(const f32x4*)(p.d_hn + row * p.hn_ld + l * H + uq);
         ext[l][tm] = e;
       }
     }
@@ -732,6 +734,201 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
 #pragma unroll
         for (int tm = 1; tm < TM; ++tm) v += dgs[l][tm][g];
         db_reduce_add(v, p.db_ih[l], p.db_hh[l], g * H + uq, lane);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, ONE LAYER per launch (rows form, L = 2 nets run layer 1, then the from-above contraction as a GEMM, then layer 0).
+// In the wavefront kernel above every member reads dg of BOTH layers (rows x 4H x 2 B each) every step: 512 KB per CU and
+// step at B = 2048, which is what bounds it (~10 TB/s of L2 reads over the chip).  A single layer only needs its own
+// W_hh^T (HU = 32 units per member: 64 KB of LDS instead of 96 KB for 16), so clusters shrink to H/32 members:
+// half as many readers per dg row and half as many rows' worth of K per step -> 128 KB per CU and step.  The from-above
+// term dg^{l+1} . W_ih^{l+1} is not recurrent: it is one (T*B x 4H x H) contraction between the two launches, handed to the
+// lower layer as its external gradient.  2T steps instead of T+1, each a quarter of the exchange.
+// ---------------------------------------------------------------------------------------------
+template <int H, int RB, int HU>
+struct ClLayerCfg {
+  static constexpr int G = 4 * H, GC = G / 8, KB = GC / 64, UT = HU / 16;
+  static constexpr int TM = RB >= 64 ? RB / 64 : 1;
+  static constexpr int WR = TM * 16;
+  static constexpr int PCH = kPanel / (WR * 16);
+  static constexpr int NPP = GC / PCH;
+  static constexpr int W_BYTES = HU * GC * 16;
+  static constexpr int SMEM = W_BYTES + 4 * kRing * kPanel;
+  static_assert(GC % 64 == 0 && GC % PCH == 0 && PCH >= 8 && HU % 16 == 0, "shape");
+};
+
+template <int H, int RB, int HU>
+__global__ __launch_bounds__(kThreads) void lstm_bwd_layer_kernel(ClBwd p) {
+  using CF = ClLayerCfg<H, RB, HU>;
+  constexpr int G = CF::G, KB = CF::KB, UT = CF::UT, TM = CF::TM, PCH = CF::PCH, NPP = CF::NPP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* ring = smem + CF::W_BYTES + wave * (kRing * kPanel);
+  const int r = lane & 15, q = lane >> 4;
+
+  const int info = cluster_join(p.sync, p.seq, (int*)(smem + CF::W_BYTES));
+  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
+  if (info < 0) return;
+  const int NU = p.NU;
+  const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
+  const int r0 = p.row0 + cluster * p.Mc;
+  const int rend = min(p.row0 + p.nrows, r0 + p.Mc);
+  if (r0 >= rend) return;
+  unsigned* flags = p.sync + kSyncFlags + cluster * 32;
+  const int u0 = me * HU;
+  const int B = p.B, T = p.T;
+  {
+    ClUnitMap um{u0};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) glds_tile<u16, HU, 64>(Wl + kb * (HU * 1024), p.w_hh_t[0], G, 0, kb * 512, um, 0, tid);
+  }
+  const int wrow0 = wave * (TM * 16);
+  const bool wact = wrow0 < RB;
+  f32x4 dcreg[TM][UT], ccur[TM][UT], dgs[TM][UT][4];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut) {
+      dcreg[tm][ut] = ccur[tm][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dgs[tm][ut][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  ClRowMap arm{r0, rend - 1};
+  auto pack4 = [](const f32x4& v) -> uint2 {
+    return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+  };
+  unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
+
+  for (int s = 0; s < T; ++s) {
+    CL_TLOG(s * 8 + 0);
+    const int t = T - 1 - s;
+    // (1) saved activations, cell states, external gradient of time t: independent of the exchange
+    uint2 gk[TM][UT][4];
+    f32x4 cprev[TM][UT], ext[TM][UT];
+    if (wact) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row0_ = r0 + wrow0 + tm * 16 + r;
+        const int64_t row = row0_ < rend ? row0_ : rend - 1;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+          const int uq = u0 + ut * 16 + q * 4;
+          const u16* gp = p.gates + ((int64_t)t * B + row) * G + uq;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gk[tm][ut][g] = *(const uint2*)(gp + g * H);
+          if (s == 0) ccur[tm][ut] = *(const f32x4*)(p.cs + ((int64_t)t * B + row) * H + uq);
+          cprev[tm][ut] = t > 0 ? *(const f32x4*)(p.cs + ((int64_t)(t - 1) * B + row) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.d_hs_top) e = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + row) * H + uq);
+          if (s == 0 && p.d_hn) e += *(const f32x4*)(p.d_hn + row * p.hn_ld + uq);
+          ext[tm][ut] = e;
+        }
+      }
+    }
+    // (2) dg of time t+1 from every member
+    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
+    CL_TLOG(s * 8 + 1);
+
+    // (3) dh = dg_{t+1} . W_hh (this member's HU units)
+    f32x4 acc[TM][UT];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int ut = 0; ut < UT; ++ut) acc[tm][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int npan = s > 0 ? NPP : 0;
+    auto issue = [&](int n) {
+      const u16* src = p.dg + ((int64_t)(t + 1) * B) * G;
+      glds_wave_panel<CF::WR, PCH>(ring + (n % kRing) * kPanel, src, G, n * PCH * 8, arm, wrow0, lane);
+    };
+    if (wact) {
+      for (int n = 0; n < kRing - 1 && n < npan; ++n) issue(n);
+      for (int n = 0; n < npan; ++n) {
+        wait_panels(npan - 1 - n < kRing - 2 ? npan - 1 - n : kRing - 2);
+        if (n + kRing - 1 < npan) issue(n + kRing - 1);
+        const char* As = ring + (n % kRing) * kPanel;
+#pragma unroll
+        for (int j = 0; j < PCH / 4; ++j) {
+          bf16x8 a[TM];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+            a[tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<PCH>(tm * 16 + r, (j << 2) | q)));
+          const int kc = n * PCH + ((j << 2) | q);
+#pragma unroll
+          for (int ut = 0; ut < UT; ++ut) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Wl + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc[tm][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[tm][ut], 0, 0, 0);
+          }
+        }
+      }
+    }
+    CL_TLOG(s * 8 + 2);
+
+    // (4) elementwise LSTM backward -> dg_t
+    if (wact) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = r0 + wrow0 + tm * 16 + r;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+          const int uq = u0 + ut * 16 + q * 4;
+          const f32x4 ig = unpack4(gk[tm][ut][0]), fg = unpack4(gk[tm][ut][1]), gg = unpack4(gk[tm][ut][2]), og = unpack4(gk[tm][ut][3]);
+          const f32x4 dh = acc[tm][ut] + ext[tm][ut];
+          f32x4 dp[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float tc = tanhf_(ccur[tm][ut][i]);
+            float dc = dh[i] * og[i] * (1.f - tc * tc);
+            if (s > 0) dc += dcreg[tm][ut][i];
+            const float d_o = dh[i] * tc;
+            const float d_i = dc * gg[i], d_f = dc * cprev[tm][ut][i], d_g = dc * ig[i];
+            dcreg[tm][ut][i] = dc * fg[i];
+            dp[0][i] = d_i * ig[i] * (1.f - ig[i]);
+            dp[1][i] = d_f * fg[i] * (1.f - fg[i]);
+            dp[2][i] = d_g * (1.f - gg[i] * gg[i]);
+            dp[3][i] = d_o * og[i] * (1.f - og[i]);
+          }
+          ccur[tm][ut] = cprev[tm][ut];
+          if (row < rend) {
+            u16* go = p.dg + ((int64_t)t * B + row) * G + uq;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              dgs[tm][ut][g] += dp[g];
+              *(uint2*)(go + g * H) = pack4(dp[g]);
+            }
+          }
+        }
+      }
+    }
+    CL_TLOG(s * 8 + 3);
+    if (s + 1 < T) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));
+    CL_TLOG(s * 8 + 4);
+  }
+  if (wact) {
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut) {
+      const int uq = u0 + ut * 16 + q * 4;
+      if (p.dgsum) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int row = r0 + wrow0 + tm * 16 + r;
+          if (row >= rend) continue;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *(f32x4*)(p.dgsum + (int64_t)row * G + g * H + uq) = dgs[tm][ut][g];
+        }
+      }
+      if (p.db_ih[0] || p.db_hh[0]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = dgs[0][ut][g];
+#pragma unroll
+          for (int tm = 1; tm < TM; ++tm) v += dgs[tm][ut][g];
+          db_reduce_add(v, p.db_ih[0], p.db_hh[0], g * H + uq, lane);
+        }
       }
     }
   }
@@ -1000,7 +1197,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
     cprevn = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + rowc) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
     extn = f32x4{0.f, 0.f, 0.f, 0.f};
     if (kp == L - 1 && p.d_hs_top) extn = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + rowc) * H + uq);
-    if (t == T - 1 && p.d_hn) extn += *(const f32x4*)(p.d_hn + rowc * (L * H) + kp * H + uq);
+    if (t == T - 1 && p.d_hn) extn += *(const f32x4*)(p.d_hn + rowc * p.hn_ld + kp * H + uq);
   };
   load_epi(0);
   const int nsteps = T + L - 1;
@@ -1280,9 +1477,87 @@ static int launch_bwd(const ClBwd& p, int RB, hipStream_t st) {
   }
 }
 
+template <int H, int RB>
+static int launch_bwd_layer(const ClBwd& p, hipStream_t st) {
+  using CF = ClLayerCfg<H, RB, 32>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_kernel<H, RB, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((lstm_bwd_layer_kernel<H, RB, 32>), dim3(kGrid), dim3(kThreads), CF::SMEM, st, p);
+  return fh_launch_status();
+}
+template <int H>
+static int launch_bwd_layer_rb(const ClBwd& p, int RB, hipStream_t st) {
+  switch (RB) {
+    case 16: return launch_bwd_layer<H, 16>(p, st);
+    case 32: return launch_bwd_layer<H, 32>(p, st);
+    case 64: return launch_bwd_layer<H, 64>(p, st);
+    default: return launch_bwd_layer<H, 128>(p, st);
+  }
+}
+
+// rows form, layer by layer (see lstm_bwd_layer_kernel): top layer first, then the from-above contraction as one GEMM into
+// bd->ws_below, then the layer below with that as its external gradient
+static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
+  const fhvae_lstm_desc* d = &bd->f;
+  const int H = (int)d->H, L = d->L;
+  constexpr int HU = 32;
+  const int NU = H / HU, NC = kGrid / NU;
+  const int64_t B = d->B, T = d->T, G = 4 * H;
+  const int64_t chunk = (int64_t)NC * 128;
+  hipLaunchKernelGGL(cluster_sync_zero_kernel, dim3(1), dim3(256), 0, st, (unsigned*)d->lp);
+  int seq = 0;
+  for (int l = L - 1; l >= 0; --l) {
+    for (int64_t row0 = 0; row0 < B; row0 += chunk) {
+      const int64_t nrows = B - row0 < chunk ? B - row0 : chunk;
+      ClBwd p = {};
+      int RB;
+      cluster_rows(nrows, NC, &p.Mc, &RB);
+      p.B = (int)B;
+      p.T = (int)T;
+      p.NU = NU;
+      p.row0 = (int)row0;
+      p.nrows = (int)nrows;
+      p.seq = seq++;
+      p.w_hh_t[0] = w.w_hh_t[l];
+      p.gates = (const u16*)d->gates + (int64_t)l * T * B * G;
+      p.cs = d->cs + (int64_t)l * T * B * H;
+      p.d_hs_top = l == L - 1 ? bd->d_hs_top : bd->ws_below;
+      p.d_hn = bd->d_hn ? bd->d_hn + (int64_t)l * H : nullptr;
+      p.hn_ld = L * H;
+      p.dg = (u16*)bd->dgates + (int64_t)l * T * B * G;
+      p.dgsum = (l == 0 && d->Ic > 0) ? bd->dgsum : nullptr;
+      p.db_ih[0] = bd->db_ih[l];
+      p.db_hh[0] = bd->db_hh[l];
+      p.sync = (unsigned*)d->lp;
+      p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
+      const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * (T - 1) * 4.0 * H);
+      const int e = H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st);
+      trace_end(st, ts);
+      if (e) return e;
+    }
+    if (l > 0) {  // ws_below[T*B, H] = dg^l [T*B, 4H] . W_ih[l]  (its transposed bf16 copy [H,4H] as the KC operand)
+      GemmParams g = {};
+      g.seg[0] = Seg{(const u16*)bd->dgates + (int64_t)l * T * B * G, G, 1, w.w_ih_t[l], G, 1, (int)G, 0};
+      g.M = (int)(T * B);
+      g.N = H;
+      g.C = bd->ws_below;
+      g.ldc = H;
+      g.splitk = 1;
+      const int e = launch_gemm(g, FHVAE_BF16, st);
+      if (e) return e;
+    }
+  }
+  return FHVAE_OK;
+}
+
 int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;
   const int H = (int)d->H, L = d->L;
+  if (cluster_form(d) == 1 && (L == 1 || bd->ws_below) && !getenv("FHVAE_NO_LAYERWISE")) return cluster_bwd_layers(bd, w, st);
   const int NU = H / 16, NC = kGrid / NU;
   const int64_t chunk = (int64_t)NC * 128;
   hipLaunchKernelGGL(cluster_sync_zero_kernel, dim3(1), dim3(256), 0, st, (unsigned*)d->lp);
@@ -1305,6 +1580,7 @@ int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStrea
     p.cs = d->cs;
     p.d_hs_top = bd->d_hs_top;
     p.d_hn = bd->d_hn;
+    p.hn_ld = L * H;
     p.dg = (u16*)bd->dgates;
     p.dgsum = d->Ic > 0 ? bd->dgsum : nullptr;
     for (int l = 0; l < L; ++l) p.db_ih[l] = bd->db_ih[l], p.db_hh[l] = bd->db_hh[l];

@@ -44,7 +44,7 @@ class LstmBwdDesc(C.Structure):
         ("dgates", _vp), ("dgsum", _vp), ("dc", _vp),
         ("dw_ih", _vp * MAX_LAYERS), ("dw_hh", _vp * MAX_LAYERS),
         ("db_ih", _vp * MAX_LAYERS), ("db_hh", _vp * MAX_LAYERS),
-        ("d_xc", _vp), ("phase", _i32),
+        ("d_xc", _vp), ("phase", _i32), ("ws_below", _vp),
     ]
 
 
@@ -122,7 +122,7 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fhvae_abi_version() != 1:
+    if lib.fhvae_abi_version() != 2:
         raise RuntimeError("libfhvae_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -590,6 +590,8 @@ class _LstmSeq(torch.autograd.Function):
         for l in range(L):
             bd.dw_ih[l], bd.dw_hh[l], bd.db_ih[l], bd.db_hh[l] = (_p(grads[4 * l + k]) for k in range(4))
         bd.d_xc = _p(d_xc)
+        ws_below = torch.empty(T, B, H, **f32) if (ctx.dtype == BF16 and L > 1) else None
+        bd.ws_below = _p(ws_below)
         if _SIDE["enabled"] and all(sk is not None for sk in ctx.sinks):
             # recurrence on this stream; the weight-gradient contractions on the side stream, joined by the optimizer
             bd.phase = 1
