@@ -230,6 +230,8 @@ def main():
         form = hb.LAST_LSTM_FORM["form"]  # which schedule the library took for this shape (fhvae_lstm_form)
         kn = {0: "lstm_%s_step_kernel", 1: "lstm_%s_cluster_kernel", 2: "lstm_%s_ksplit_kernel"}[form]
         names = {0: kn % "fwd", 1: kn % "bwd"}
+        if form == 1 and not os.environ.get("FHVAE_NO_LAYERWISE"):
+            names[1] = "lstm_bwd_layer_kernel"  # rows form: the backward runs one persistent launch per layer
         if not cells:  # FC model: no LSTM cells to trace
             cells = {0: (1, 1e-9, 0.0)}
         dom = max(cells, key=lambda k: cells[k][1])
