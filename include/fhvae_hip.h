@@ -256,6 +256,15 @@ int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, i
                        const float* g_scale, float g_mul, float* dq, float* dtable, void* ws,
                        int64_t B, int64_t S, int64_t D, void* stream);
 
+/* The discriminative segment variational lower bound, train_model.py:243-251:
+ *   loss = -mean_b(lower_bound[b] + alpha * log_qy) = -(mean(lower_bound) + alpha * log_qy)   (log_qy one f32 on the device)
+ * and its backward d_lower_bound[b] = -g/B, d_log_qy = -alpha*g (g = *g_loss, NULL = 1): one launch each instead of the
+ * ~10 elementwise/reduction launches of the expression. */
+int fhvae_loss_fwd(const float* lower_bound, const float* log_qy, float alpha, float* loss, int64_t B,
+                   void* stream);
+int fhvae_loss_bwd(const float* g_loss, float alpha, float* d_lower_bound, float* d_log_qy, int64_t B,
+                   void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Adam (train_model.py:409-411: torch.optim.Adam(lr, betas=(beta_one, beta_two)), eps 1e-8, no
  * weight decay) over one flat f32 buffer; step_count is read from device memory (int32, already

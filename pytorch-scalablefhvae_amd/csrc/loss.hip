@@ -330,6 +330,25 @@ __global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) / (float)B;
 }
 
+// loss = -(mean(lower_bound) + alpha * log_qy)  (train_model.py:243-251) in one launch, and its backward in one
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ lb, const float* __restrict__ log_qy, float alpha,
+                                                       float* __restrict__ out, int B) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) s += lb[b];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = -((red[0] + red[1] + red[2] + red[3]) / (float)B + alpha * log_qy[0]);
+}
+__global__ void loss_bwd_kernel(const float* __restrict__ g, float alpha, float* __restrict__ d_lb, float* __restrict__ d_qy,
+                                int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float gv = g ? g[0] : 1.f;
+  if (i < B) d_lb[i] = -gv / (float)B;
+  if (i == 0 && d_qy) d_qy[0] = -alpha * gv;
+}
+
 __global__ void disc_rescale_kernel(const float* __restrict__ rmax, const float* __restrict__ rsum,
                                     const float* __restrict__ m, float* __restrict__ out, int64_t B) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -750,5 +769,23 @@ extern "C" int fhvae_adam_step(float* p, const float* g, float* m, float* v, voi
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (u16*)p_lp, n, lr,
                      beta1, beta2, eps, grad_scale, step_count);
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_loss_fwd(const float* lower_bound, const float* log_qy, float alpha, float* loss, int64_t B, void* stream) {
+  FH_CHECK_PTR(lower_bound);
+  FH_CHECK_PTR(log_qy);
+  FH_CHECK_PTR(loss);
+  FH_CHECK_POS(B);
+  FH_CHECK_I32(B);
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lower_bound, log_qy, alpha, loss, (int)B);
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_loss_bwd(const float* g_loss, float alpha, float* d_lower_bound, float* d_log_qy, int64_t B, void* stream) {
+  FH_CHECK_PTR(d_lower_bound);
+  FH_CHECK_POS(B);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)fh_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, g_loss, alpha, d_lower_bound,
+                     d_log_qy, B);
   return fh_launch_status();
 }

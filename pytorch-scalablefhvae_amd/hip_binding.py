@@ -81,6 +81,8 @@ SIGNATURES = {
     "fhvae_gauss_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fhvae_gauss_head_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_gauss_head_bwd_lp": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_loss_fwd": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _vp]),
+    "fhvae_loss_bwd": (C.c_int, [_vp, _f32, _vp, _vp, _i64, _vp]),
     "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_form": (C.c_int, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
@@ -740,6 +742,35 @@ def elbo(x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2, num_segs, layout, refer
     if reference_detach:  # simple_fhvae.py:114: the decoder outputs are detached -> its graph is not reached
         x_mu, x_lv = x_mu.detach(), x_lv.detach()
     return _Elbo.apply(x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2, num_segs, layout, bool(reference_detach))
+
+
+class _FusedLoss(torch.autograd.Function):
+    """loss = -(mean(lower_bound) + alpha * log_qy), train_model.py:243-251, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, lower_bound, log_qy, alpha):
+        _need_gpu(lower_bound, log_qy)
+        lib = load_library()
+        lb, qy = _f32c(lower_bound), _f32c(log_qy)
+        out = torch.empty((), device=lb.device, dtype=torch.float32)
+        with _Timed("fhvae_loss_fwd"):
+            _check(lib.fhvae_loss_fwd(_p(lb), _p(qy), float(alpha), _p(out), lb.numel(), _stream()), "fhvae_loss_fwd")
+        ctx.alpha, ctx.B = float(alpha), lb.numel()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        g = _f32c(g)
+        d_lb = torch.empty(ctx.B, device=g.device, dtype=torch.float32)
+        d_qy = torch.empty((), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        with _Timed("fhvae_loss_bwd"):
+            _check(lib.fhvae_loss_bwd(_p(g), ctx.alpha, _p(d_lb), _p(d_qy), ctx.B, _stream()), "fhvae_loss_bwd")
+        return d_lb, d_qy, None
+
+
+def fused_loss(lower_bound, log_qy, alpha):
+    return _FusedLoss.apply(lower_bound, log_qy, float(alpha))
 
 
 def raw_disc_fwd(q, table, idx, row0=0, want_ce=True):

@@ -277,3 +277,21 @@ def test_fused_adam_arena_matches_torch_adam(hb):
     for a, b in zip(mine, ref):
         close(a, b, rtol=1e-5, what="fused adam")
     assert all(p.data_ptr() == v.data_ptr() for p, v in zip(mine, o_mine.p_arena.views))
+
+
+def test_fused_loss_matches_expression(hb):
+    """train_model.loss_function on the model's GPU outputs = fhvae_loss_fwd/bwd: same value and gradients as the
+    reference expression -mean(lower_bound + alpha*log_qy) (train_model.py:243-251)."""
+    import train_model
+
+    torch.manual_seed(5)
+    lb = torch.randn(777, device="cuda").mul_(50).requires_grad_(True)
+    qy = torch.randn((), device="cuda").requires_grad_(True)
+    loss = train_model.loss_function(lb, qy, 10.0)
+    (loss * 3.0).backward()
+    lb2, qy2 = lb.detach().clone().requires_grad_(True), qy.detach().clone().requires_grad_(True)
+    want = -1 * torch.mean(lb2 + 10.0 * qy2)
+    (want * 3.0).backward()
+    close(loss, want, rtol=1e-5, what="loss")
+    close(lb.grad, lb2.grad, rtol=1e-6, what="d_lb")
+    close(qy.grad, qy2.grad, rtol=1e-6, what="d_qy")
