@@ -206,6 +206,21 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
   // 128x128 tiles (half the L2->LDS traffic per FLOP) once the problem offers enough of them
   // (measured: with fewer than ~2 workgroups per CU the per-CU load bandwidth, not the aggregate L2 traffic,
   // is the limit, and 64x64 tiles on more CUs win: 2048x1024x512 bf16 takes 11 us with 64^2, 21 us with 128^2)
+  // long-K bf16 weight gradients (KM/KM, K = T*B >= 16384): 128x64 tiles with 128-k panels (a third less operand traffic per
+  // FLOP than 64x64; 56 KB of LDS = two workgroups per CU) and exactly as many K slices as fill the chip twice over
+  // (512 workgroups).  1024x256 over K = 40960: 52 -> 43 us; other slice counts were slower (256: -6 %, 768: -4 % per step).
+  if (bf && want_auto && ktot >= 16384 && p.M >= 128 && p.seg[1].K == 0 && !p.seg[0].a_kc && !p.seg[0].b_kc && !getenv("FHVAE_NO_12864")) {
+    const int64_t tiles = fh_cdiv(p.M, 128) * fh_cdiv(p.N, 64);
+    int64_t sk = fh_cdiv(512, tiles);
+    const int64_t panels = fh_cdiv(ktot, 128);
+    if (sk > panels / 2) sk = panels / 2;
+    if (sk < 1) sk = 1;
+    p.splitk = (int)sk;
+    if (p.splitk > 1) p.mode = 2;
+    dim3 grid((unsigned)fh_cdiv(p.N, 64), (unsigned)fh_cdiv(p.M, 128), (unsigned)p.splitk);
+    hipLaunchKernelGGL((gemm_kernel<u16, 128, 64, 4, 1, 16, false, false>), grid, dim3(kThreads), 0, st, p);
+    return fh_launch_status();
+  }
   const bool big = kmax > 16 * epc && fh_cdiv(p.M, 128) * fh_cdiv(p.N, 128) >= 512;
   const int tb = big ? 128 : 64;
   const int ch = big ? 16 : (kmax <= 16 * epc ? 8 : 32);
