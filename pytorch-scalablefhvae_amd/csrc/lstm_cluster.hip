@@ -757,11 +757,16 @@ struct ClLayerCfg {
   static constexpr int NPP = GC / PCH;
   static constexpr int W_BYTES = HU * GC * 16;
   static constexpr int SMEM = W_BYTES + 4 * kRing * kPanel;
+  static constexpr int SMEM_HW = SMEM + 4 * 8192;  // + the helper wave's operand buffer
   static_assert(GC % 64 == 0 && GC % PCH == 0 && PCH >= 8 && HU % 16 == 0, "shape");
 };
 
-template <int H, int RB, int HU>
-__global__ __launch_bounds__(kThreads) void lstm_bwd_layer_kernel(ClBwd p) {
+// HW (RB <= 64): a fifth wave does nothing but fetch the epilogue operands of step s+1 (saved gates, c_{t-1}, the external
+// gradient: HBM) into LDS with LDS-DMA while the four compute waves work on step s.  Loads return in order per wave: issued
+// by the compute waves themselves these loads sit in front of the flag poll (2.1 us of every 6.5-us step), and fetching them
+// a step ahead from the same waves only moved the stall (the dg stores then queue behind them).
+template <int H, int RB, int HU, bool HW>
+__global__ __launch_bounds__(HW ? kThreads + 64 : kThreads) void lstm_bwd_layer_kernel(ClBwd p) {
   using CF = ClLayerCfg<H, RB, HU>;
   constexpr int G = CF::G, KB = CF::KB, UT = CF::UT, TM = CF::TM, PCH = CF::PCH, NPP = CF::NPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -784,10 +789,50 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_kernel(ClBwd p) {
   {
     ClUnitMap um{u0};
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) glds_tile<u16, HU, 64>(Wl + kb * (HU * 1024), p.w_hh_t[0], G, 0, kb * 512, um, 0, tid);
+    for (int kb = 0; kb < KB; ++kb)
+      if (tid < kThreads) glds_tile<u16, HU, 64>(Wl + kb * (HU * 1024), p.w_hh_t[0], G, 0, kb * 512, um, 0, tid);
   }
+  static_assert(!HW || TM == 1, "the helper wave serves 16-row tiles");
   const int wrow0 = wave * (TM * 16);
-  const bool wact = wrow0 < RB;
+  const bool helper = HW && wave == 4;
+  const bool wact = wrow0 < RB && !helper;
+  char* ops = smem + CF::W_BYTES + 4 * kRing * kPanel;  // HW: [tile][gates 4 KB | c_prev 2 KB | ext 2 KB]
+  // helper: operands of step sn for every 16-row tile of the workgroup, one contiguous KB per DMA instruction
+  auto fetch = [&](int sn) {
+    const int t = T - 1 - sn;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w * 16 >= RB) break;
+      char* op = ops + w * 8192;
+      {
+        const int rl = lane >> 2, piece = lane & 3;
+        const int row0_ = r0 + w * 16 + rl;
+        const int64_t row = row0_ < rend ? row0_ : rend - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u16* src = p.gates + ((int64_t)t * B + row) * G + g * H + u0 + piece * 8;
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                           (void __attribute__((address_space(3)))*)(op + g * 1024), 16, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rl = i * 8 + (lane >> 3), piece = lane & 7;
+        const int row0_ = r0 + w * 16 + rl;
+        const int64_t row = row0_ < rend ? row0_ : rend - 1;
+        if (t > 0) {
+          const float* src = p.cs + ((int64_t)(t - 1) * B + row) * H + u0 + piece * 4;
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                           (void __attribute__((address_space(3)))*)(op + 4096 + i * 1024), 16, 0, 0);
+        }
+        if (p.d_hs_top) {
+          const float* src = p.d_hs_top + ((int64_t)t * B + row) * H + u0 + piece * 4;
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                           (void __attribute__((address_space(3)))*)(op + 6144 + i * 1024), 16, 0, 0);
+        }
+      }
+    }
+  };
   f32x4 dcreg[TM][UT], ccur[TM][UT], dgs[TM][UT][4];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
@@ -802,6 +847,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_kernel(ClBwd p) {
     return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
   };
   unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
+  if constexpr (HW) {
+    if (helper) fetch(0);
+    __syncthreads();  // weights and the operands of step 0 have landed
+  }
 
   for (int s = 0; s < T; ++s) {
     CL_TLOG(s * 8 + 0);
@@ -809,6 +858,28 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_kernel(ClBwd p) {
     // (1) saved activations, cell states, external gradient of time t: independent of the exchange
     uint2 gk[TM][UT][4];
     f32x4 cprev[TM][UT], ext[TM][UT];
+    if constexpr (HW) {
+      if (wact) {
+        const char* op = ops + wave * 8192;
+        const int row0_ = r0 + wrow0 + r;
+        const int64_t row = row0_ < rend ? row0_ : rend - 1;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+          const int ul = ut * 16 + q * 4, uq = u0 + ul;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gk[0][ut][g] = *(const uint2*)(op + g * 1024 + r * 64 + ul * 2);
+          cprev[0][ut] = t > 0 ? *(const f32x4*)(op + 4096 + r * 128 + ul * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 e = p.d_hs_top ? *(const f32x4*)(op + 6144 + r * 128 + ul * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (s == 0) {
+            ccur[0][ut] = *(const f32x4*)(p.cs + ((int64_t)t * B + row) * H + uq);
+            if (p.d_hn) e += *(const f32x4*)(p.d_hn + row * p.hn_ld + uq);
+          }
+          ext[0][ut] = e;
+        }
+      }
+      __syncthreads();                      // every compute wave holds its operands: the helper may refill the buffer
+      if (helper && s + 1 < T) fetch(s + 1);  // (its vmcnt is drained in front of the publish barrier below)
+    } else
     if (wact) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
@@ -830,7 +901,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_kernel(ClBwd p) {
       }
     }
     // (2) dg of time t+1 from every member
-    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
+    if (s > 0 && !helper && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
     CL_TLOG(s * 8 + 1);
 
     // (3) dh = dg_{t+1} . W_hh (this member's HU units)
@@ -1480,13 +1551,20 @@ static int launch_bwd(const ClBwd& p, int RB, hipStream_t st) {
 template <int H, int RB>
 static int launch_bwd_layer(const ClBwd& p, hipStream_t st) {
   using CF = ClLayerCfg<H, RB, 32>;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_kernel<H, RB, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+  constexpr bool HW = RB <= 64 && CF::SMEM_HW <= 163840;  // helper wave where its operand buffer fits
+  constexpr int SMEM = HW ? CF::SMEM_HW : CF::SMEM;
+  const bool hw = HW && !getenv("FHVAE_NO_HELPER");
+  static bool attr[2] = {false, false};
+  if (!attr[hw]) {
+    hipError_t e = hw ? hipFuncSetAttribute((const void*)lstm_bwd_layer_kernel<H, RB, 32, HW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM)
+                      : hipFuncSetAttribute((const void*)lstm_bwd_layer_kernel<H, RB, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr[hw] = true;
   }
-  hipLaunchKernelGGL((lstm_bwd_layer_kernel<H, RB, 32>), dim3(kGrid), dim3(kThreads), CF::SMEM, st, p);
+  if (hw)
+    hipLaunchKernelGGL((lstm_bwd_layer_kernel<H, RB, 32, HW>), dim3(kGrid), dim3(kThreads + 64), SMEM, st, p);
+  else
+    hipLaunchKernelGGL((lstm_bwd_layer_kernel<H, RB, 32, false>), dim3(kGrid), dim3(kThreads), CF::SMEM, st, p);
   return fh_launch_status();
 }
 template <int H>
