@@ -358,7 +358,7 @@ class _GaussHead(torch.autograd.Function):
                                                     _p(lv), _p(smp), M, K, D, F32, _stream()), "fhvae_gauss_head_reparam_fwd")
         ctx.save_for_backward(h, w_mu, w_lv, eps, lv)
         if smp is None:
-            smp = mu.new_zeros(())  # placeholder output, never differentiable
+            smp = mu.new_empty(())  # placeholder output (value never read), never differentiable
             ctx.mark_non_differentiable(smp)
         return mu, lv, smp
 
@@ -417,7 +417,7 @@ class _GaussHeadLp(torch.autograd.Function):
                                                     _p(smp), M, K, D, BF16, _stream()), "fhvae_gauss_head_reparam_fwd")
         ctx.save_for_backward(h_lp, wt, eps, lv)
         if smp is None:
-            smp = mu.new_zeros(())
+            smp = mu.new_empty(())  # placeholder (value never read)
             ctx.mark_non_differentiable(smp)
         return mu, lv, smp
 
@@ -557,7 +557,7 @@ class _LstmSeq(torch.autograd.Function):
         ctx.x_lp = x_lp
         ctx.save_for_backward(x_tm, xc, hs, cs, gates, lp, *params)
         if top == 0:
-            out = hn.new_zeros(())  # placeholder: this net's per-step states are not an output
+            out = hn.new_empty(())  # placeholder (value never read): this net's per-step states are not an output
             ctx.mark_non_differentiable(out)
             return out, hn
         out = hs_top if bf else hs[L - 1]
