@@ -1,28 +1,36 @@
-// lstm_cluster.hip -- K1 in its persistent form: the whole bf16 recurrence of a net (all T steps, all layers) in ONE
-// launch of 256 workgroups, one per CU.
+// lstm_cluster.hip -- K1 in its persistent form: the bf16 recurrence of a net (all T steps) in ONE launch of 256
+// workgroups, one per CU, instead of one launch per wavefront step.
 //
 // Why: one launch per wavefront step costs a dependent kernel boundary plus a cold start of every tile (27 us per
 // step at B = 2048, 11 us at B = 256).  The recurrence only couples the HIDDEN UNITS of one batch row, so the batch is
-// cut into CLUSTERS of NU = H/16 workgroups that never talk to another cluster; a cluster is formed from workgroups
-// of ONE XCD (HW_REG_XCC_ID), so everything its members exchange stays in that XCD's L2:
-//   * workgroup `me` of a cluster owns hidden units [16 me, 16 me + 16) of EVERY layer: its 64 gate columns of W_hh[l]
-//     (and W_ih[l], l >= 1) live in LDS for the whole launch (H = 256, L = 2: 96 KB), the cell state c of its
-//     (row, unit) pairs lives in registers;
-//   * per wavefront step s (layer l at time s - l) the only shared data is h^l_{s-l-1} (bf16, written once, at a fresh
-//     address: hs is the saved-for-backward buffer anyway); it is BOTH the recurrent operand of layer l and the input
-//     of layer l+1, so it is staged once (LDS-DMA, 16-KB panels, double buffered) and multiplied into both
-//     accumulators;
+// cut into CLUSTERS of workgroups that never talk to another cluster; a cluster is formed from workgroups of ONE XCD
+// (HW_REG_XCC_ID), so everything its members exchange stays in that XCD's L2:
+//   * a member owns a slice of the hidden units: its gate columns of W_hh (and W_ih of the layer above) live in LDS for the
+//     whole launch, the cell state c (forward) / dc and the bias-gradient sums (backward) live in registers;
+//   * per step the only shared data is h (forward) / dg (backward) of the previous step, bf16, written once at a fresh
+//     address (they are the saved-for-backward / weight-gradient operands anyway);
 //   * hand-off per step: plain stores -> s_waitcnt vmcnt(0) (the write-through L1 has delivered them to the XCD's L2)
-//     -> workgroup barrier -> one agent-scope flag store; consumers poll the NU flags of their cluster with L1-bypassing
-//     loads, then read h with sc1 loads.  No agent-scope fence: an L2 write-back / invalidate costs 17+ us per step
-//     (tools/exp/xcd_barrier.hip: 1.1-1.4 us per step for this form, 17-27 us with fences) and is not needed inside
+//     -> workgroup barrier -> one agent-scope flag store; every wave polls the flags of its cluster with L1-bypassing
+//     loads, then reads the operand with sc1 loads.  No agent-scope fence: an L2 write-back / invalidate costs 17+ us per
+//     step (tools/exp/xcd_barrier.hip: 1.1-1.4 us per step for this form, 17-27 us with fences) and is not needed inside
 //     one XCD.  The same-XCD premise is not assumed from blockIdx: a workgroup reads its XCD from the hardware
 //     register and takes a slot by an atomic ticket on that XCD's counter; if an XCD ever received more than 32
-//     workgroups the launch aborts (status word, NaN outputs), it never computes from a stale line.
+//     workgroups the launch aborts (status word), it never computes from a stale line;
 //   * every spin is bounded and watches the abort word: a lost workgroup ends the launch, it cannot hang the GPU.
+// Kernels (H in {128, 256}, L <= 2; chosen by rows per cluster, cluster_form):
+//   lstm_fwd_cluster_kernel   forward, both layers as one wavefront, 16 units per member, 64/128 rows per cluster; every
+//                             wave stages its own rows with LDS-DMA into a private ring (no barrier in the contraction);
+//                             the layer-0 input projection folded in (W_ih[0] fragments in registers)
+//   lstm_bwd_layer_kernel     backward of ONE layer per launch, 32 units per member (a quarter of the wavefront kernel's
+//                             exchange bytes per step), a helper wave fetching the epilogue operands; the from-above term
+//                             is a GEMM between the two launches (cluster_bwd_layers)
+//   lstm_bwd_cluster_kernel   backward as one wavefront (FHVAE_NO_LAYERWISE=1; superseded at these shapes)
+//   lstm_fwd/bwd_ksplit_kernel  <= 32 rows per cluster (B <= 512): the waves split the CONTRACTION, operands go
+//                             global -> registers from a blocked exchange buffer, partial tiles are summed through LDS
 //
 // Semantics are those of lstm.hip's step kernels (same accumulation order per k is NOT promised: parity is the bf16
-// tolerance of the model tests).  f32 (parity mode) stays on the per-step kernels.
+// tolerance of the model tests, and tests/test_lstm_cluster_gpu.py compares the two schedules directly).  f32 (parity
+// mode) stays on the per-step kernels.
 #include "lstm_cluster.h"
 
 #include <cstdlib>
