@@ -83,6 +83,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--hierarchical", dest="sample_hierarchical", action="store_true",   # train_model.py:203-214
                    help="re-estimate the mu2 table in closed form from the encoder before training (utils.py:45-60)")
     p.add_argument("--compute-dtype", default="f32", choices=["f32", "bf16"])
+    p.add_argument("--hip-graph", action="store_true",
+                   help="capture one training step (zero_grad, forward, loss, backward, Adam) into a hipGraph and replay it for "
+                        "every full-size batch (static input buffers; a smaller last batch runs eagerly)")
     p.add_argument("--paper-objective", action="store_true",
                    help="train the intended objective (decoder attached, log_qy=-CE) instead of the reference's literal one")
     return p
@@ -175,6 +178,45 @@ def main(argv=None) -> int:
 
         save_args(args.exp_dir, args)  # train_model.py:422
 
+    def train_step(idxs, features, nsegs):
+        """One iteration of the reference loop body, train_model.py:446-454."""
+        optimizer.zero_grad()
+        lower_bound, discrim_loss, log_px_z, neg_kld_z1, neg_kld_z2, log_pmu2 = model(features, idxs, S, nsegs)
+        loss = loss_function(lower_bound, discrim_loss, args.alpha_dis)
+        loss.backward()
+        optimizer.step()
+        return loss.detach(), lower_bound.detach()
+
+    graph = None  # --hip-graph: (CUDAGraph, static inputs, static outputs), built on the first full-size batch
+
+    def graph_step(idxs, features, nsegs):
+        nonlocal graph
+        bsz = args.training_batch_size
+        idxs = torch.as_tensor(idxs).to(device=device, dtype=torch.int64)
+        nsegs = torch.as_tensor(nsegs).to(device=device, dtype=torch.int64)
+        if not args.hip_graph or features.shape[0] != bsz:
+            return train_step(idxs, features, nsegs)
+        if graph is None:
+            st_i, st_x, st_n = idxs.clone(), features.clone(), nsegs.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up outside the capture (lazy initialisations, allocator pools)
+                    train_step(st_i, st_x, st_n)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = train_step(st_i, st_x, st_n)
+            graph = (g, (st_i, st_x, st_n), outs)
+            return outs  # (the two warm-up steps and the capture trained on this batch)
+        g, (st_i, st_x, st_n), outs = graph
+        st_i.copy_(idxs)
+        st_x.copy_(features)
+        st_n.copy_(nsegs)
+        g.replay()
+        return outs
+
     best_epoch, best_val_lb = 0, -np.inf
     for epoch in range(args.epochs):
         model.train()
@@ -182,12 +224,8 @@ def main(argv=None) -> int:
         train_loss = torch.zeros((), device=device)
         nb = 0
         for idxs, features, nsegs in train_batches():
-            optimizer.zero_grad()
-            lower_bound, discrim_loss, log_px_z, neg_kld_z1, neg_kld_z2, log_pmu2 = model(features, idxs, S, nsegs)
-            loss = loss_function(lower_bound, discrim_loss, args.alpha_dis)
-            loss.backward()
-            optimizer.step()
-            train_loss += loss.detach()
+            loss, lower_bound = graph_step(idxs, features, nsegs)
+            train_loss += loss
             nb += 1
             if torch.isnan(lower_bound).any():
                 print("Training diverged")
