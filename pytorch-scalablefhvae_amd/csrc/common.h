@@ -56,5 +56,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
   // tanh(x) = 1 - 2/(1+exp(2x)); exp overflow -> rcp(inf) = 0 -> 1, underflow -> 1-2 = -1
-  return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+  // (an explicit fma: left to -ffp-contract the compiler fused this differently in different unrolled copies of an
+  //  epilogue, and a row's result then depended on which tile slot of a wave it occupied)
+  return __builtin_fmaf(-2.0f, __frcp_rn(1.0f + __expf(2.0f * x)), 1.0f);
 }

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
       }
       const float ig = sigmoidf_(acc[tm][0][r] + pa[0]), fg = sigmoidf_(acc[tm][1][r] + pa[1]);
       const float gg = tanhf_(acc[tm][2][r] + pa[2]), og = sigmoidf_(acc[tm][3][r] + pa[3]);
-      const float c = fg * cp + ig * gg;
+      const float c = __builtin_fmaf(fg, cp, ig * gg);
       const float h = og * tanhf_(c);
       J.c_out[(int64_t)row * H + unit] = c;
       store_h<T>(J.h_out + (int64_t)row * H + unit, h);

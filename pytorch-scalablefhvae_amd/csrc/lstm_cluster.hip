@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float ig = sigmoidf_(gv[0][i]), fg = sigmoidf_(gv[1][i]), gg = tanhf_(gv[2][i]), og = sigmoidf_(gv[3][i]);
-            c[i] = fg * creg[ll][tm][i] + ig * gg;
+            c[i] = __builtin_fmaf(fg, creg[ll][tm][i], ig * gg);  // (explicit: see tanhf_)
             h[i] = og * tanhf_(c[i]);
             gv[0][i] = ig, gv[1][i] = fg, gv[2][i] = gg, gv[3][i] = og;
           }
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float ig = sigmoidf_(gv[0][i]), fg = sigmoidf_(gv[1][i]), gg = tanhf_(gv[2][i]), og = sigmoidf_(gv[3][i]);
-        c[i] = fg * creg[i] + ig * gg;
+        c[i] = __builtin_fmaf(fg, creg[i], ig * gg);
         hreg[i] = og * tanhf_(c[i]);
         gv[0][i] = ig, gv[1][i] = fg, gv[2][i] = gg, gv[3][i] = og;
       }

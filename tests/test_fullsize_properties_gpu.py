@@ -86,3 +86,32 @@ def test_gather_scatter_adjoint_fullsize(hb):
     hb.raw_scatter_rows_(dt, u, idx)
     # <gather(table), u> == <table, scatter(u)>
     close((rows * u).sum(), (table * dt).sum(), rtol=1e-4, what="adjoint")
+
+
+@pytest.mark.parametrize("B", [256, 2048])
+def test_bf16_lstm_rows_are_independent_fullsize(hb, B):
+    """configs[1] shape (2x256 LSTM, T=20, F=80), bf16 persistent kernels: a segment's outputs and its contribution to the
+    gradients do not depend on where it sits in the batch -- permuting the batch rows permutes hs/hn BIT FOR BIT (rows only
+    meet in the weight gradients), and the weight gradients of the permuted batch agree to split-K summation order.  The
+    persistent kernels cut the batch into clusters / row tiles / waves: any cross-row leak or stale exchange shows here."""
+    T, I, H, L = 20, 80, 256, 2
+    torch.manual_seed(11)
+    lstm = torch.nn.LSTM(I, H, L)
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    x = torch.randn(T, B, I).cuda()
+    g1, g2 = torch.randn(T, B, H).cuda(), torch.randn(B, L * H).cuda()
+    perm = torch.randperm(B).cuda()
+
+    def run(xx, a, b):
+        params = [getattr(lstm, n).detach().cuda().requires_grad_(True) for n in names]
+        hs, hn = hb.lstm_seq(xx, None, T, params, hb.BF16)
+        ((hs * a).sum() + (hn * b).sum()).backward()
+        torch.cuda.synchronize()
+        return hs.detach(), hn.detach(), [p.grad for p in params]
+
+    hs, hn, gr = run(x, g1, g2)
+    hs_p, hn_p, gr_p = run(x[:, perm].contiguous(), g1[:, perm].contiguous(), g2[perm].contiguous())
+    assert hb.lstm_sync_status() == 0
+    assert torch.equal(hs[:, perm], hs_p) and torch.equal(hn[perm], hn_p)
+    for a, b, n in zip(gr, gr_p, names):
+        close(b, a, rtol=2e-3, what="permutation invariance of d" + n)
