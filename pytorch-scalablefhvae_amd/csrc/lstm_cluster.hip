@@ -1382,6 +1382,184 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, one layer per launch, CONTRACTION-SPLIT form (H = 256, at most 32 rows per cluster = 2048 rows per launch):
+// a member owns 64 units (its W_hh^T slice: 128 KB of LDS), so a cluster has only H/64 = 4 members and a step's exchange is
+// 32 rows x 4H x 2 B = 64 KB per CU (the 32-unit kernel above: 128 KB, the wavefront kernel: 512 KB).  The four waves split K:
+// wave kp loads its quarter of the k-steps for all rows straight into registers (blocked exchange buffer: a fragment is 1 KB
+// contiguous), the partial tiles are summed through LDS, wave w finishes unit tile w.  Epilogue operands are fetched one step
+// ahead (as in lstm_bwd_ksplit_kernel).
+// ---------------------------------------------------------------------------------------------
+template <int H, int RT>
+__global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
+  constexpr int HU = 64, UT = 4;
+  constexpr int G = 4 * H, GC = G / 8, KB = GC / 64, KS = G / 32, KPW = KS / 4;
+  constexpr int W_BYTES = HU * GC * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;
+  char* Part = smem + W_BYTES;  // [wave][RT][UT] tiles of 1 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int kp = wave;
+
+  const int info = cluster_join(p.sync, p.seq, (int*)Part);
+  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
+  if (info < 0) return;
+  const int NU = p.NU;
+  const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
+  const int r0 = p.row0 + cluster * p.Mc;
+  const int rend = min(p.row0 + p.nrows, r0 + p.Mc);
+  if (r0 >= rend) return;
+  unsigned* flags = p.sync + kSyncFlags + cluster * 32;
+  const int u0 = me * HU;
+  const int uq = u0 + wave * 16 + q * 4;  // epilogue: wave w finishes unit tile w of every row tile
+  const int B = p.B, T = p.T;
+  {
+    ClUnitMap um{u0};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) glds_tile<u16, HU, 64>(Wl + kb * (HU * 1024), p.w_hh_t[0], G, 0, kb * 512, um, 0, tid);
+  }
+  int row[RT];
+  int64_t rowc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    row[rt] = r0 + rt * 16 + r;
+    rowc[rt] = row[rt] < rend ? row[rt] : rend - 1;
+  }
+  f32x4 dcreg[RT], ccur[RT], dgs[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    dcreg[rt] = ccur[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dgs[rt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto pack4 = [](const f32x4& v) -> uint2 {
+    return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+  };
+  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(p.xch);
+  unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
+  __syncthreads();  // weights have landed (and every thread has read the join word)
+
+  uint2 gkn[RT][4];
+  f32x4 cprevn[RT], extn[RT], ccurn[RT];
+  auto load_epi = [&](int sn) {
+    const int t = T - 1 - sn;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const u16* gp = p.gates + ((int64_t)t * B + rowc[rt]) * G + uq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gkn[rt][g] = *(const uint2*)(gp + g * H);
+      if (sn == 0) ccurn[rt] = *(const f32x4*)(p.cs + ((int64_t)t * B + rowc[rt]) * H + uq);
+      cprevn[rt] = t > 0 ? *(const f32x4*)(p.cs + ((int64_t)(t - 1) * B + rowc[rt]) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.d_hs_top) e = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + rowc[rt]) * H + uq);
+      if (sn == 0 && p.d_hn) e += *(const f32x4*)(p.d_hn + rowc[rt] * p.hn_ld + uq);
+      extn[rt] = e;
+    }
+  };
+  load_epi(0);
+  for (int s = 0; s < T; ++s) {
+    CL_TLOG(s * 8 + 0);
+    const int t = T - 1 - s;
+    uint2 gk[RT][4], dpk[RT][4];
+    f32x4 cprev[RT], ext[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gk[rt][g] = gkn[rt][g];
+      cprev[rt] = cprevn[rt];
+      ext[rt] = extn[rt];
+      if (s == 0) ccur[rt] = ccurn[rt];
+    }
+    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
+    CL_TLOG(s * 8 + 1);
+
+    f32x4 acc[RT][UT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ut = 0; ut < UT; ++ut) acc[rt][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      uint4 a[RT][KPW];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int64_t base = (xch_off((s - 1) & 1, 0, 1, KS, kp * KPW, B, rowc[rt]) + q * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) a[rt][j] = load_sc1(dg_rs, base + j * (B * 64));
+      }
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) {
+        const int kc = ((kp * KPW + j) << 2) | q;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+          const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Wl + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, __builtin_bit_cast(bf16x8, a[rt][j]), acc[rt][ut], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ut = 0; ut < UT; ++ut) *(f32x4*)(Part + ((wave * RT + rt) * UT + ut) * 1024 + lane * 16) = acc[rt][ut];
+    if (s + 1 < T) load_epi(s + 1);
+    __syncthreads();
+    CL_TLOG(s * 8 + 2);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 dh = ext[rt];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dh += *(const f32x4*)(Part + ((k * RT + rt) * UT + wave) * 1024 + lane * 16);
+      const f32x4 ig = unpack4(gk[rt][0]), fg = unpack4(gk[rt][1]), gg = unpack4(gk[rt][2]), og = unpack4(gk[rt][3]);
+      f32x4 dp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float tc = tanhf_(ccur[rt][i]);
+        float dc = dh[i] * og[i] * (1.f - tc * tc);
+        if (s > 0) dc += dcreg[rt][i];
+        const float d_o = dh[i] * tc;
+        const float d_i = dc * gg[i], d_f = dc * cprev[rt][i], d_g = dc * ig[i];
+        dcreg[rt][i] = dc * fg[i];
+        dp[0][i] = d_i * ig[i] * (1.f - ig[i]);
+        dp[1][i] = d_f * fg[i] * (1.f - fg[i]);
+        dp[2][i] = d_g * (1.f - gg[i] * gg[i]);
+        dp[3][i] = d_o * og[i] * (1.f - og[i]);
+      }
+      ccur[rt] = cprev[rt];
+      if (row[rt] < rend) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          dgs[rt][g] += dp[g];
+          dpk[rt][g] = pack4(dp[g]);
+          *(uint2*)(p.xch + xch_off(s & 1, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];  // what the members wait for
+        }
+      }
+    }
+    CL_TLOG(s * 8 + 3);
+    if (s + 1 < T) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));  // (its barrier also frees Part)
+    else __syncthreads();
+    CL_TLOG(s * 8 + 4);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (row[rt] >= rend) continue;
+      u16* go = p.dg + ((int64_t)t * B + row[rt]) * G + uq;  // the row-major copy the weight-gradient contractions read
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = dpk[rt][g];
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      v += dgs[rt][g];
+      if (p.dgsum && row[rt] < rend) *(f32x4*)(p.dgsum + (int64_t)row[rt] * G + g * H + uq) = dgs[rt][g];
+    }
+    if (p.db_ih[0] || p.db_hh[0]) db_reduce_add(v, p.db_ih[0], p.db_hh[0], g * H + uq, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static bool device_ok() {
@@ -1585,15 +1763,32 @@ static int launch_bwd_layer_rb(const ClBwd& p, int RB, hipStream_t st) {
   }
 }
 
+template <int RT>
+static int launch_bwd_layer_ks(const ClBwd& p, hipStream_t st) {
+  constexpr int SMEM = 64 * (4 * 256 / 8) * 16 + 4 * RT * 4 * 1024;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_ks_kernel<256, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((lstm_bwd_layer_ks_kernel<256, RT>), dim3(kGrid), dim3(kThreads), SMEM, st, p);
+  return fh_launch_status();
+}
+
 // rows form, layer by layer (see lstm_bwd_layer_kernel): top layer first, then the from-above contraction as one GEMM into
 // bd->ws_below, then the layer below with that as its external gradient
 static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;
   const int H = (int)d->H, L = d->L;
-  constexpr int HU = 32;
+  // H = 256: 64 units per member with the waves splitting K (2048 rows per launch); else 32 units per member, waves split rows
+  // (measured: B = 1024: 544k vs 515k segments/s, 2048: 743k vs 728k; from 4096 rows on the 32-unit kernel with 128 rows per
+  //  cluster wins, 868k vs 833k: the contraction-split launch holds 2048 rows)
+  const bool ks = H == 256 && d->B <= 2048 && !getenv("FHVAE_NO_LAYER_KS");
+  const int HU = ks ? 64 : 32;
   const int NU = H / HU, NC = kGrid / NU;
   const int64_t B = d->B, T = d->T, G = 4 * H;
-  const int64_t chunk = (int64_t)NC * 128;
+  const int64_t chunk = (int64_t)NC * (ks ? 32 : 128);
   hipLaunchKernelGGL(cluster_sync_zero_kernel, dim3(1), dim3(256), 0, st, (unsigned*)d->lp);
   int seq = 0;
   for (int l = L - 1; l >= 0; --l) {
@@ -1621,7 +1816,9 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.sync = (unsigned*)d->lp;
       p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
       const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * (T - 1) * 4.0 * H);
-      const int e = H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st);
+      p.xch = w.xch;
+      const int e = ks ? (RB <= 16 ? launch_bwd_layer_ks<1>(p, st) : launch_bwd_layer_ks<2>(p, st))
+                       : (H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st));
       trace_end(st, ts);
       if (e) return e;
     }
