@@ -149,16 +149,19 @@ def test_fhvae_bf16_tracks_f32(hb):
     assert all(torch.isfinite(p.grad).all() for n, p in m.named_parameters() if n != "mu2_table")
 
 
-def test_distributed_wrapper_world1_matches_single_gpu(hb):
+@pytest.mark.parametrize("H,B,dtype,port", [(32, 48, "f32", 29617), (256, 64, "bf16", 29618), (256, 1024, "bf16", 29619)])
+def test_distributed_wrapper_world1_matches_single_gpu(hb, H, B, dtype, port):
     """dist_shard.DistributedFHVAE on a 1-rank RCCL group (the HipBackend code path of the sharded ops):
-    same losses as the plain single-GPU loop over several Adam steps."""
+    same losses as the plain single-GPU loop over several Adam steps.  The bf16 cases run the persistent LSTM kernels
+    (contraction-split and rows form): there the runner reduces the first two gradient buckets from its hook between a
+    net's recurrence and its parameter gradients."""
     import torch.distributed as dist
     from dist_shard import DistributedFHVAE
     from fhvae import FHVAE
     from hip_optim import FusedAdam
     from train_model import loss_function
 
-    T, F, H, D, B, S = 20, 80, 32, 16, 48, 37
+    T, F, D, S = 20, 80, 16, 37
     x = torch.randn(B, T, F, generator=torch.Generator().manual_seed(1)).cuda()
     idx = torch.randint(0, S, (B,), generator=torch.Generator().manual_seed(2)).cuda()
     ns = torch.randint(20, 200, (B,), generator=torch.Generator().manual_seed(3)).cuda()
@@ -167,7 +170,7 @@ def test_distributed_wrapper_world1_matches_single_gpu(hb):
 
     def build():
         torch.manual_seed(11)
-        return FHVAE(T * F, [H, H], [H, H], D, D, [H, H], num_seqs=S, reference_compat=False).cuda()
+        return FHVAE(T * F, [H, H], [H, H], D, D, [H, H], num_seqs=S, reference_compat=False, compute_dtype=dtype).cuda()
 
     m1 = build()
     opt = FusedAdam(m1.parameters(), lr=1e-3, betas=(0.95, 0.999))
@@ -180,7 +183,7 @@ def test_distributed_wrapper_world1_matches_single_gpu(hb):
         opt.step()
         ref_losses.append(loss.item())
 
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1,
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
         m2 = build()
@@ -190,9 +193,11 @@ def test_distributed_wrapper_world1_matches_single_gpu(hb):
         got = [runner.train_step(x, idx, ns, alpha=10.0)[0].item() for _ in range(3)]
     finally:
         dist.destroy_process_group()
+    assert hb.lstm_sync_status() == 0
+    tol = 1e-4 if dtype == "f32" else 2e-3  # bf16: the bias-gradient atomics sum in a different order run to run
     for a, b in zip(got, ref_losses):
-        assert abs(a - b) <= 1e-4 * abs(b), (got, ref_losses)
-    close(runner.shard, m1.mu2_table, rtol=1e-4, what="table after 3 steps")
+        assert abs(a - b) <= tol * abs(b), (got, ref_losses)
+    close(runner.shard, m1.mu2_table, rtol=tol, what="table after 3 steps")
 
 
 def test_fused_adam_grad_sinks_match_torch_adam(hb):
