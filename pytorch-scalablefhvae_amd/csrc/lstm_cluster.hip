@@ -1579,6 +1579,7 @@ bool cluster_eligible(const fhvae_lstm_desc* d) {
   if (d->dtype != FHVAE_BF16 || !d->lp) return false;
   if (d->H != 256 && d->H != 128) return false;
   if (d->L > 2 || d->T + d->L >= kSeqEpochs) return false;
+  if (d->B > 131072) return false;  // 32-bit byte offsets into the exchange buffer (buffer loads)
   return device_ok();
 }
 
