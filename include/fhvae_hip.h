@@ -132,9 +132,12 @@ typedef struct fhvae_lstm_desc {
   float* hn;     /* (B, L*H) f32: final hidden state of every layer, concatenated (may be NULL) */
   float* hs_top_f32; /* (T,B,H) f32 copy of the top layer's h_t (BF16 mode, may be NULL; in F32 mode
                         the top layer is hs + (L-1)*T*B*H and this must be NULL) */
-  float* pre;    /* workspace (T,B,4H) f32 (I > 0) or (B,4H) (I == 0): layer-0 input projection */
+  float* pre;    /* workspace (T,B,4H) f32 (I > 0) or (B,4H) (I == 0): layer-0 input projection (the persistent
+                    schedules only use its first (B,4H): they multiply x_t by W_ih[0] inside the kernel) */
   void* lp;      /* BF16 mode: workspace of fhvae_lstm_lp_bytes() bytes; the forward fills it with bf16
-                    copies of x, xc, the weights and the transposed weights, the backward reuses it */
+                    copies of x, xc, the weights and the transposed weights, the backward reuses it.  It also
+                    holds the persistent schedules' sync block (first FHVAE_LSTM_SYNC_BYTES) and their exchange
+                    buffer (2*L*B*4H bf16): keep it alive and untouched between the forward and its backward */
 } fhvae_lstm_desc;
 
 int64_t fhvae_lstm_lp_bytes(const fhvae_lstm_desc* d);
