@@ -34,7 +34,7 @@ CONFIGS = {
     "c2": dict(H=256, L=2, D=32, S=4600, T=20, F=80, B=2048, alt_B=256, desc="fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 4.6k-seq mu2 table"),
     "c3": dict(H=256, L=2, D=32, S=28000, T=20, F=80, B=2048, desc="same model, 28k-seq mu2 table, batch 2048"),
     "c4": dict(H=512, L=2, D=32, S=100000, T=20, F=80, B=2048, desc="2x512 LSTM, 100k-seq mu2 table"),
-    "c5": dict(H=256, L=2, D=32, S=1000000, T=40, F=80, B=2048, desc="1M-seq mu2 table, 40-frame segments, fp32"),
+    "c5": dict(H=256, L=2, D=32, S=1000000, T=40, F=80, B=2048, dtype="f32", desc="1M-seq mu2 table, 40-frame segments, fp32"),
 }
 
 
@@ -92,8 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
-                    help="MFMA operand type of the LSTM nets (configs[1] is quoted in bf16; f32 = exact-f32 parity mode)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"],
+                    help="MFMA operand type of the LSTM nets (default: the config's -- bf16, configs[4] f32; f32 = exact-f32 parity mode)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the whole step")
     ap.add_argument("--force-dist", action="store_true", help="use the distributed runner even with one rank (testing)")
@@ -129,6 +129,7 @@ def main():
 
     hb.load_library()
     cfg = CONFIGS[args.config]
+    args.dtype = args.dtype or cfg.get("dtype", "bf16")
     B = args.batch or cfg["B"]
     H, L, D, S, T, F = (cfg[k] for k in "HLDSTF")
     torch.manual_seed(0)
