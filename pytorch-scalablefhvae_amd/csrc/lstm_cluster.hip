@@ -35,6 +35,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "gemm_core.h"
 #include "gemm_launch.h"
@@ -201,6 +202,7 @@ struct ClFwd {
   u16* xch;  // exchange buffer (blocked copy of h; contraction-split form), see xch_off
   unsigned* sync;
   unsigned long long* tlog;  // optional phase clock log of cluster 0 / member 0 (tools/prof_cluster.py)
+  int il;                    // rows form, L = 2: layer 0's gate math between the MFMAs of the h^1 panels
 };
 
 template <int H, int L, int RB>
@@ -368,6 +370,8 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     f32x4 acc[L][TM][4];
 #pragma unroll
     for (int l = 0; l < L; ++l) zero_acc(acc[l]);
+    f32x4 g0v[TM][4];   // layer 0's pre-activations, then its activated gates (interleaved form)
+    bool did0 = false;  // layer 0's gate math already ran inside the contraction
     const int lo = s - T > 0 ? s - T : 0;
     const int hi = s - 1 < L - 1 ? s - 1 : L - 1;
     const int npan = hi >= lo ? (hi - lo + 1) * NPP : 0;
@@ -390,44 +394,134 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
                                                                       acc[0][tm][g], 0, 0, 0);
         }
       }
-      for (int n = 0; n < npan; ++n) {
+      // L = 2, both sources present (every step from s = 2 on): the h^1 panels are multiplied by an unrolled loop below that
+      // carries layer 0's gate math between its MFMAs (layer 0's accumulators are final once the h^0 panels are done)
+      const bool two = L == 2 && hi > lo && p.il;
+      const int npan_a = two ? NPP : npan;
+      for (int n = 0; n < npan_a; ++n) {
         wait_panels(npan - 1 - n < kRing - 2 ? npan - 1 - n : kRing - 2);  // panel n has landed
         if (n + kRing - 1 < npan) issue(n + kRing - 1);  // into the slot consumed one iteration ago
         const int l = lo + n / NPP, pp = n % NPP;
         const char* As = ring + (n % kRing) * kPanel;
+        {
+          // one panel of source ll: every fragment of a k-step (TM of h, 4 of W_hh[ll], 4 of W_ih[ll+1]) is requested before
+          // its MFMAs -- ONE LDS round trip per k-step (a read per MFMA pair costs 8: a wave is alone on its SIMD, nothing
+          // hides that latency); REC = layer ll itself is active at this step
+          auto panel = [&](auto ll_c, auto rec_c) {
+            constexpr int ll = decltype(ll_c)::value;
+            constexpr bool REC = decltype(rec_c)::value;
+            constexpr bool UP = ll + 1 < L;
+            constexpr int lu = UP ? ll + 1 : L - 1;
+            const char* Whh = Wl + (2 * ll) * CF::W_BYTES;
+            const char* Wih = Wl + (2 * ll + 1) * CF::W_BYTES;  // of layer ll+1 (exists when UP)
+            constexpr int NJ = PCH / 4, NB = (REC ? 4 : 0) + (UP ? 4 : 0);
+            bf16x8 a[2][TM], bh[2][4], bu[2][4];
+            auto frags = [&](int j, int buf) {
+              const int kc = pp * PCH + ((j << 2) | q);
 #pragma unroll
-        for (int ll = 0; ll < L; ++ll) {
-          if (ll != l) continue;
-          const bool rec = s - ll < T;  // layer ll itself is active at this step
-          const char* Whh = Wl + (2 * ll) * CF::W_BYTES;
-          const char* Wih = Wl + (2 * ll + 1) * CF::W_BYTES;  // of layer ll+1 (exists when ll+1 < L)
-#pragma unroll 2
-          for (int j = 0; j < PCH / 4; ++j) {
-            bf16x8 a[TM];
+              for (int tm = 0; tm < TM; ++tm)
+                a[buf][tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<PCH>(tm * 16 + r, (j << 2) | q)));
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                if constexpr (REC) bh[buf][g] = __builtin_bit_cast(bf16x8, *(const uint4*)(Whh + kc_off<HC>(g * 16 + r, kc)));
+                if constexpr (UP) bu[buf][g] = __builtin_bit_cast(bf16x8, *(const uint4*)(Wih + kc_off<HC>(g * 16 + r, kc)));
+              }
+            };
+            frags(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + NB, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              if (j + 1 < NJ) frags(j + 1, (j + 1) & 1);  // the next k-step's fragments fly under this one's MFMAs
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                  if constexpr (REC) acc[ll][tm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j & 1][g], a[j & 1][tm], acc[ll][tm][g], 0, 0, 0);
+                  if constexpr (UP) acc[lu][tm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bu[j & 1][g], a[j & 1][tm], acc[lu][tm][g], 0, 0, 0);
+                }
+              if (j + 1 < NJ) {
+#pragma unroll
+                for (int i = 0; i < TM + NB; ++i) {
+                  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * NB - (TM + NB), 0);
+              } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * NB, 0);
+              }
+            }
+          };
+          if (l == 0) {
+            if (s < T)
+              panel(std::integral_constant<int, 0>{}, std::true_type{});
+            else
+              panel(std::integral_constant<int, 0>{}, std::false_type{});
+          }
+          if constexpr (L > 1) {
+            if (l == 1) {
+              if (s - 1 < T)
+                panel(std::integral_constant<int, 1>{}, std::true_type{});
+              else
+                panel(std::integral_constant<int, 1>{}, std::false_type{});
+            }
+          }
+        }
+      }
+      if constexpr (L == 2) {
+        if (two) {
+          if (s < T) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
-              a[tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<PCH>(tm * 16 + r, (j << 2) | q)));
-            const int kc = pp * PCH + ((j << 2) | q);
-            if (rec) {
 #pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Whh + kc_off<HC>(g * 16 + r, kc)));
+              for (int g = 0; g < 4; ++g) g0v[tm][g] = acc[0][tm][g] + padd[tm][g];
+          }
+          // chunk c = (tile c / 4, element c % 4) of layer 0's gate math: 10 transcendentals + the cell update of 1 (row, unit)
+          auto g0_chunk = [&](int c) {
+            const int tm = c >> 2, i = c & 3;
+            const float ig = sigmoidf_(g0v[tm][0][i]), fg = sigmoidf_(g0v[tm][1][i]), gg = tanhf_(g0v[tm][2][i]), og = sigmoidf_(g0v[tm][3][i]);
+            const float cn = __builtin_fmaf(fg, creg[0][tm][i], ig * gg);
+            creg[0][tm][i] = cn;
+            hreg[0][tm][i] = og * tanhf_(cn);
+            g0v[tm][0][i] = ig, g0v[tm][1][i] = fg, g0v[tm][2][i] = gg, g0v[tm][3][i] = og;
+          };
+          auto second = [&](auto with_gates) {
+            constexpr bool WG = decltype(with_gates)::value;
+            constexpr int KS1 = NPP * (PCH / 4), NCH = TM * 4;  // k-steps of the h^1 source, gate chunks of layer 0
+            const char* Whh = Wl + 2 * CF::W_BYTES;
+#pragma unroll
+            for (int pp = 0; pp < NPP; ++pp) {
+              const int n = NPP + pp;
+              wait_panels(2 * NPP - 1 - n < kRing - 2 ? 2 * NPP - 1 - n : kRing - 2);
+              if (n + kRing - 1 < 2 * NPP) issue(n + kRing - 1);
+              const char* As = ring + (n % kRing) * kPanel;
+#pragma unroll
+              for (int j = 0; j < PCH / 4; ++j) {
+                bf16x8 a[TM], b[4];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
-                  acc[ll][tm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[ll][tm][g], 0, 0, 0);
+                  a[tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<PCH>(tm * 16 + r, (j << 2) | q)));
+                const int kc = pp * PCH + ((j << 2) | q);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b[g] = __builtin_bit_cast(bf16x8, *(const uint4*)(Whh + kc_off<HC>(g * 16 + r, kc)));
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                  for (int tm = 0; tm < TM; ++tm)
+                    acc[1][tm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[g], a[tm], acc[1][tm][g], 0, 0, 0);
+                if constexpr (WG) {
+                  const int kk = pp * (PCH / 4) + j;
+#pragma unroll
+                  for (int c = 0; c < NCH; ++c)
+                    if (c >= kk * NCH / KS1 && c < (kk + 1) * NCH / KS1) g0_chunk(c);
+                }
               }
             }
-            if (ll + 1 < L) {
-              constexpr int kTop = L - 1;
-              const int lu = ll + 1 < L ? ll + 1 : kTop;  // (constant after unrolling; the guard keeps the index in range)
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Wih + kc_off<HC>(g * 16 + r, kc)));
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-                  acc[lu][tm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[lu][tm][g], 0, 0, 0);
-              }
-            }
+          };
+          if (s < T) {
+            second(std::true_type{});
+            did0 = true;
+          } else {
+            second(std::false_type{});
           }
         }
       }
@@ -448,6 +542,12 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
           const int row = r0 + wrow0 + tm * 16 + r;
+          if (ll == 0 && did0) {  // computed between the MFMAs of the h^1 panels
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gpk[0][tm][g] = pack4(g0v[tm][g]);
+            if (row < rend) *(uint2*)(p.hs + (lt * B + row) * H + uq) = pack4(hreg[0][tm]);
+            continue;
+          }
           f32x4 gv[4], c, h;
 #pragma unroll
           for (int g = 0; g < 4; ++g) gv[g] = acc[ll][tm][g] + (ll == 0 ? padd[tm][g] : bias[ll][g]);
@@ -929,18 +1029,34 @@ __global__ __launch_bounds__(HW ? kThreads + 64 : kThreads) void lstm_bwd_layer_
         wait_panels(npan - 1 - n < kRing - 2 ? npan - 1 - n : kRing - 2);
         if (n + kRing - 1 < npan) issue(n + kRing - 1);
         const char* As = ring + (n % kRing) * kPanel;
-#pragma unroll
-        for (int j = 0; j < PCH / 4; ++j) {
-          bf16x8 a[TM];
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-            a[tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<PCH>(tm * 16 + r, (j << 2) | q)));
+        // every fragment of a k-step is requested before its MFMAs, the next k-step's fly under them (one exposed LDS round
+        // trip per panel: a wave is alone on its SIMD, nothing else hides that latency)
+        constexpr int NJ = PCH / 4;
+        bf16x8 a[2][TM], b[2][UT];
+        auto frags = [&](int j, int buf) {
           const int kc = n * PCH + ((j << 2) | q);
 #pragma unroll
-          for (int ut = 0; ut < UT; ++ut) {
-            const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Wl + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
+          for (int tm = 0; tm < TM; ++tm)
+            a[buf][tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<PCH>(tm * 16 + r, (j << 2) | q)));
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) acc[tm][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[tm][ut], 0, 0, 0);
+          for (int ut = 0; ut < UT; ++ut)
+            b[buf][ut] = __builtin_bit_cast(bf16x8, *(const uint4*)(Wl + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
+        };
+        frags(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + UT, 0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (j + 1 < NJ) frags(j + 1, (j + 1) & 1);
+#pragma unroll
+          for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc[tm][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j & 1][ut], a[j & 1][tm], acc[tm][ut], 0, 0, 0);
+          if (j + 1 < NJ) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + UT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * UT - 1, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * UT, 0);
           }
         }
       }
@@ -1679,6 +1795,7 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     p.xch = w.xch;
     p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
     p.seq = (int)(row0 / chunk);
+    p.il = getenv("FHVAE_NO_FWD_IL") ? 0 : 1;
     double fl = 0;
     for (int l = 0; l < L; ++l) fl += 2.0 * nrows * 4 * H * ((l > 0 ? d->T * H : 0) + (d->T - 1) * (double)H);
     const int ts = trace_begin(st, kTraceFwdCell, fl);
