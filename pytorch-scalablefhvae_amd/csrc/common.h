@@ -53,10 +53,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // Gate nonlinearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the libm
 // expf/tanhf expand to ~30-40 instructions with branches and made the cell epilogue cost more than its GEMM.
 // Absolute error ~1e-7 on values in (-1,1): inside the 1e-4 parity budget (checked by the LSTM parity tests).
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// (__builtin_amdgcn_rcpf = one v_rcp_f32, 1 ulp; __frcp_rn expands to the ten-instruction correctly-rounded division)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
   // tanh(x) = 1 - 2/(1+exp(2x)); exp overflow -> rcp(inf) = 0 -> 1, underflow -> 1-2 = -1
   // (an explicit fma: left to -ffp-contract the compiler fused this differently in different unrolled copies of an
   //  epilogue, and a row's result then depended on which tile slot of a wave it occupied)
-  return __builtin_fmaf(-2.0f, __frcp_rn(1.0f + __expf(2.0f * x)), 1.0f);
+  return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)), 1.0f);
 }
