@@ -15,6 +15,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libfhvae_hip.so")
 SOURCES = ["gemm.hip", "lstm.hip", "lstm_cluster.hip", "loss.hip", "disc_mfma.hip", "data.hip", "trace.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
+EXTRA_FLAGS = {}  # per-file additions
 
 
 def _newer(a, b):
@@ -39,7 +40,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + os.environ.get("FHVAE_EXTRA_HIPCC", "").split() + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))

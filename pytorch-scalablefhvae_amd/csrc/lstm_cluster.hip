@@ -1602,16 +1602,26 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
         for (int j = 0; j < KPW; ++j) a[rt][j] = load_sc1(dg_rs, base + j * (B * 64));
       }
-#pragma unroll
-      for (int j = 0; j < KPW; ++j) {
+      // the weight fragments do not depend on the exchange: those of a k-step are requested together, one k-step ahead of
+      // their MFMAs (the first ones while the exchange loads are still in flight) -- a read per MFMA pair put an exposed LDS
+      // round trip in front of every pair
+      bf16x8 b[2][UT];
+      auto wfrags = [&](int j, int buf) {
         const int kc = ((kp * KPW + j) << 2) | q;
 #pragma unroll
-        for (int ut = 0; ut < UT; ++ut) {
-          const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Wl + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
+        for (int ut = 0; ut < UT; ++ut)
+          b[buf][ut] = __builtin_bit_cast(bf16x8, *(const uint4*)(Wl + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
+      };
+      wfrags(0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // every exchange load is in flight before the first MFMA (the scheduler sinks them otherwise)
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) {
+        if (j + 1 < KPW) wfrags(j + 1, (j + 1) & 1);
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
-            acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, __builtin_bit_cast(bf16x8, a[rt][j]), acc[rt][ut], 0, 0, 0);
-        }
+            acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j & 1][ut], __builtin_bit_cast(bf16x8, a[rt][j]), acc[rt][ut], 0, 0, 0);
       }
     }
 #pragma unroll
