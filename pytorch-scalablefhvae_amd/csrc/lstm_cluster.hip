@@ -1243,6 +1243,24 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
     for (int l = 0; l < L; ++l)
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[l][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the weight fragments do not depend on the exchange: all those of a source are requested together while the exchange
+    // loads are in flight (a read in front of every MFMA exposed an LDS round trip per MFMA: a wave is alone on its SIMD)
+    bf16x8 wh[L][KPW][4], wu[L][KPW][4];
+    auto wfrags = [&](int l) {
+      const char* Whh = Wl + (2 * l) * W_BYTES;
+      const char* Wih = Wl + (2 * l + 1) * W_BYTES;
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) {
+        const int kc = ((kp * KPW + j) << 2) | q;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          wh[l][j][g] = __builtin_bit_cast(bf16x8, *(const uint4*)(Whh + kc_off<HC>(g * 16 + r, kc)));
+          if (l + 1 < L) wu[l][j][g] = __builtin_bit_cast(bf16x8, *(const uint4*)(Wih + kc_off<HC>(g * 16 + r, kc)));
+        }
+      }
+    };
+    wfrags(0);
+    __builtin_amdgcn_sched_barrier(0);
     if (fold && s < T) {
 #pragma unroll
       for (int jj = 0; jj < KSXW; ++jj)
@@ -1253,28 +1271,22 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
+      if (l + 1 < L) wfrags(l + 1);  // the next source's fragments fly under this one's MFMAs
       const int tau = s - l - 1;
       if (tau < 0 || tau >= T) continue;
       const bool rec = s - l < T;
-      const char* Whh = Wl + (2 * l) * W_BYTES;
-      const char* Wih = Wl + (2 * l + 1) * W_BYTES;
 #pragma unroll
       for (int j = 0; j < KPW; ++j) {
         const bf16x8 av = __builtin_bit_cast(bf16x8, a[l][j]);
-        const int kc = ((kp * KPW + j) << 2) | q;
         if (rec) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            acc[l][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(Whh + kc_off<HC>(g * 16 + r, kc))), av,
-                                                                acc[l][g], 0, 0, 0);
+          for (int g = 0; g < 4; ++g) acc[l][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[l][j][g], av, acc[l][g], 0, 0, 0);
         }
         if (l + 1 < L) {
           constexpr int kTop = L - 1;
           const int lu = l + 1 < L ? l + 1 : kTop;
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            acc[lu][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(Wih + kc_off<HC>(g * 16 + r, kc))), av,
-                                                                 acc[lu][g], 0, 0, 0);
+          for (int g = 0; g < 4; ++g) acc[lu][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[l][j][g], av, acc[lu][g], 0, 0, 0);
         }
       }
     }
@@ -1422,22 +1434,35 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
 #pragma unroll
       for (int j = 0; j < KPW; ++j) a[l][j] = load_sc1(dg_rs, base + j * (B * 64));
     }
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const int tau = T - s + (L - 1 - l);
-      if (s == 0 || tau < 0 || tau > T - 1) continue;
-      const bool rec = tau - 1 >= 0;
+    // the weight fragments do not depend on the exchange: those of a source are requested together while the exchange loads
+    // are in flight, the next source's under this one's MFMAs (a read in front of every MFMA exposed an LDS round trip each)
+    bf16x8 wh[L][KPW], wu[L][KPW];
+    auto wfrags = [&](int l) {
       const char* Whh = Wl + (2 * l) * W_BYTES;
       const char* Wih = Wl + (l > 0 ? 2 * l - 1 : 0) * W_BYTES;
 #pragma unroll
       for (int j = 0; j < KPW; ++j) {
-        const bf16x8 av = __builtin_bit_cast(bf16x8, a[l][j]);
         const int kc = ((kp * KPW + j) << 2) | q;
         const int woff = (kc >> 6) * 16384 + kc_off<64>(r, kc & 63);
-        if (rec) acc[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(Whh + woff)), av, acc[l], 0, 0, 0);
+        wh[l][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(Whh + woff));
+        if (l > 0) wu[l][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(Wih + woff));
+      }
+    };
+    if (s > 0) wfrags(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      if (l + 1 < L && s > 0) wfrags(l + 1);
+      const int tau = T - s + (L - 1 - l);
+      if (s == 0 || tau < 0 || tau > T - 1) continue;
+      const bool rec = tau - 1 >= 0;
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a[l][j]);
+        if (rec) acc[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[l][j], av, acc[l], 0, 0, 0);
         if (l > 0) {
           const int ld = l > 0 ? l - 1 : 0;
-          acc[ld] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(Wih + woff)), av, acc[ld], 0, 0, 0);
+          acc[ld] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[l][j], av, acc[ld], 0, 0, 0);
         }
       }
     }
