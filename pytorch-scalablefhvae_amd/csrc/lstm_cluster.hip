@@ -1533,11 +1533,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
 template <int H, int RT>
 __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
   constexpr int HU = 64, UT = 4;
-  constexpr int G = 4 * H, GC = G / 8, KB = GC / 64, KS = G / 32, KPW = KS / 4;
-  constexpr int W_BYTES = HU * GC * 16;
+  constexpr int G = 4 * H, KS = G / 32, KPW = KS / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Wl = smem;
-  char* Part = smem + W_BYTES;  // [wave][RT][UT] tiles of 1 KB
+  char* Part = smem;  // [wave][RT][UT] tiles of 1 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int kp = wave;
@@ -1554,11 +1552,14 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
   const int u0 = me * HU;
   const int uq = u0 + wave * 16 + q * 4;  // epilogue: wave w finishes unit tile w of every row tile
   const int B = p.B, T = p.T;
-  {
-    ClUnitMap um{u0};
+  // wave kp multiplies the same KPW k-steps of W_hh^T against every step's dg: its 32 weight fragments (128 registers) are
+  // loaded ONCE and stay in registers -- the contraction reads no LDS at all
+  bf16x8 wreg[KPW][UT];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) glds_tile<u16, HU, 64>(Wl + kb * (HU * 1024), p.w_hh_t[0], G, 0, kb * 512, um, 0, tid);
-  }
+  for (int j = 0; j < KPW; ++j)
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut)
+      wreg[j][ut] = __builtin_bit_cast(bf16x8, *(const uint4*)(p.w_hh_t[0] + (int64_t)(u0 + ut * 16 + r) * G + ((((kp * KPW + j) << 2) | q) << 3)));
   int row[RT];
   int64_t rowc[RT];
 #pragma unroll
@@ -1627,27 +1628,14 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
         for (int j = 0; j < KPW; ++j) a[rt][j] = load_sc1(dg_rs, base + j * (B * 64));
       }
-      // the weight fragments do not depend on the exchange: those of a k-step are requested together, one k-step ahead of
-      // their MFMAs (the first ones while the exchange loads are still in flight) -- a read per MFMA pair put an exposed LDS
-      // round trip in front of every pair
-      bf16x8 b[2][UT];
-      auto wfrags = [&](int j, int buf) {
-        const int kc = ((kp * KPW + j) << 2) | q;
-#pragma unroll
-        for (int ut = 0; ut < UT; ++ut)
-          b[buf][ut] = __builtin_bit_cast(bf16x8, *(const uint4*)(Wl + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
-      };
-      wfrags(0, 0);
       __builtin_amdgcn_sched_barrier(0);  // every exchange load is in flight before the first MFMA (the scheduler sinks them otherwise)
 #pragma unroll
-      for (int j = 0; j < KPW; ++j) {
-        if (j + 1 < KPW) wfrags(j + 1, (j + 1) & 1);
+      for (int j = 0; j < KPW; ++j)
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
-            acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j & 1][ut], __builtin_bit_cast(bf16x8, a[rt][j]), acc[rt][ut], 0, 0, 0);
-      }
+            acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][ut], __builtin_bit_cast(bf16x8, a[rt][j]), acc[rt][ut], 0, 0, 0);
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -1918,7 +1906,7 @@ static int launch_bwd_layer_rb(const ClBwd& p, int RB, hipStream_t st) {
 
 template <int RT>
 static int launch_bwd_layer_ks(const ClBwd& p, hipStream_t st) {
-  constexpr int SMEM = 64 * (4 * 256 / 8) * 16 + 4 * RT * 4 * 1024;
+  constexpr int SMEM = 4 * RT * 4 * 1024;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_ks_kernel<256, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
