@@ -1535,7 +1535,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
   constexpr int HU = 64, UT = 4;
   constexpr int G = 4 * H, KS = G / 32, KPW = KS / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Part = smem;  // [wave][RT][UT] tiles of 1 KB
+  char* Part = smem;                       // [wave][RT][UT] tiles of 1 KB
+  char* Stg = smem + 4 * RT * UT * 1024;   // dg of this step, [RT * 16 rows][4 gates][64 units] bf16 (row stride kStgRow)
+  constexpr int kStgRow = 4 * HU * 2 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int kp = wave;
@@ -1671,6 +1673,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
           dgs[rt][g] += dp[g];
           dpk[rt][g] = pack4(dp[g]);
           *(uint2*)(p.xch + xch_off(s & 1, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];  // what the members wait for
+          *(uint2*)(Stg + (rt * 16 + r) * kStgRow + g * (HU * 2) + (wave * 16 + q * 4) * 2) = dpk[rt][g];
         }
       }
     }
@@ -1678,12 +1681,21 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
     if (s + 1 < T) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));  // (its barrier also frees Part)
     else __syncthreads();
     CL_TLOG(s * 8 + 4);
+    // the row-major copy the weight-gradient contractions read leaves through the LDS image as whole 128-byte lines (a lane's
+    // own values are 8-byte pieces of 16 different lines per instruction)
+    {
+      uint4 v[RT * 2];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      if (row[rt] >= rend) continue;
-      u16* go = p.dg + ((int64_t)t * B + row[rt]) * G + uq;  // the row-major copy the weight-gradient contractions read
+      for (int i = 0; i < RT * 2; ++i) {
+        const int c = (wave * RT * 2 + i) * 64 + lane, idx = c >> 3;  // 16-byte chunk c of the image: (row, gate) idx, chunk c & 7
+        v[i] = *(const uint4*)(Stg + (idx >> 2) * kStgRow + (idx & 3) * (HU * 2) + (c & 7) * 16);
+      }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = dpk[rt][g];
+      for (int i = 0; i < RT * 2; ++i) {
+        const int c = (wave * RT * 2 + i) * 64 + lane, idx = c >> 3;
+        const int rw = r0 + (idx >> 2);
+        if (rw < rend) *(uint4*)(p.dg + ((int64_t)t * B + rw) * G + (idx & 3) * H + u0 + (c & 7) * 8) = v[i];
+      }
     }
   }
 #pragma unroll
@@ -1906,7 +1918,7 @@ static int launch_bwd_layer_rb(const ClBwd& p, int RB, hipStream_t st) {
 
 template <int RT>
 static int launch_bwd_layer_ks(const ClBwd& p, hipStream_t st) {
-  constexpr int SMEM = 4 * RT * 4 * 1024;
+  constexpr int SMEM = 4 * RT * 4 * 1024 + RT * 16 * (4 * 64 * 2 + 16);
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_ks_kernel<256, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
