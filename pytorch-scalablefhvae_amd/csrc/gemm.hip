@@ -11,6 +11,45 @@ namespace fh {
 // ---------------------------------------------------------------------------------------------
 // generic GEMM kernel: C = epi(sum_seg A.B^T)
 // ---------------------------------------------------------------------------------------------
+// four consecutive columns of one row (col % 4 == 0): 16-byte stores when the output allows it
+__device__ __forceinline__ void gemm_store4(const GemmParams& p, bool vec, int row, int col, f32x4 v) {
+  if (p.relu) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  if (vec && col + 3 < p.N) {
+    if (p.C) {
+      float* c = (p.C2 && row >= p.c_split) ? p.C2 + (int64_t)(row - p.c_split) * p.ldc + col : p.C + (int64_t)row * p.ldc + col;
+      if (p.mode == 0) {
+        *(f32x4*)c = v;
+      } else if (p.mode == 1) {
+        *(f32x4*)c = *(const f32x4*)c + v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(c + i, v[i]);
+      }
+    }
+    if (p.Clp)
+      *(uint2*)(p.Clp + (int64_t)row * p.ldclp + col) =
+          uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (col + i >= p.N) break;
+    float* c = p.C ? ((p.C2 && row >= p.c_split) ? p.C2 + (int64_t)(row - p.c_split) * p.ldc + col + i : p.C + (int64_t)row * p.ldc + col + i) : nullptr;
+    if (c) {
+      if (p.mode == 0)
+        *c = v[i];
+      else if (p.mode == 1)
+        *c += v[i];
+      else
+        atomicAdd(c, v[i]);
+    }
+    if (p.Clp) p.Clp[(int64_t)row * p.ldclp + col + i] = f2bf(v[i]);
+  }
+}
+
 __device__ __forceinline__ void gemm_store(const GemmParams& p, int row, int col, float v) {
   if (p.relu) v = fmaxf(v, 0.f);
   if (p.C) {
@@ -26,7 +65,10 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, int row, int col
 }
 
 // one output tile (bx, by) of problem p, K slice bz of p.splitk
-template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool DMA>
+// SWAP (outputs written once, no split-K atomics): MFMA roles swapped so that a lane holds 4 consecutive columns of a row and
+// row-major f32 / bf16 outputs leave as 16- / 8-byte stores (the unswapped layout gives 4-byte stores; its split-K atomics,
+// 64 contiguous bytes per 16 lanes, stay as they are: swapped they scatter and ran 25 % slower)
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool DMA, bool SWAP>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bx, int by, int bz, char* smem) {
   using TL = Tile<T, BM, BN, WM, WN, CH>;
   constexpr int TM = TL::TM, TN = TL::TN;
@@ -47,34 +89,62 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bx, int by, i
   if constexpr (kDma)
     dma = p.splitk == 1 && m0 + BM <= p.M && n0 + BN <= p.N && seg_glds_ok<T>(p.seg[0], TL::BK) && seg_glds_ok<T>(p.seg[1], TL::BK);
   if (dma) {
-    if constexpr (kDma) mainloop_glds<T, BM, BN, WM, WN, CH, NBUF>(acc, p.seg, m0, n0, arm, brm, smem);
+    if constexpr (kDma) mainloop_glds<T, BM, BN, WM, WN, CH, NBUF, SWAP>(acc, p.seg, m0, n0, arm, brm, smem);
   } else {
-    mainloop<T, BM, BN, WM, WN, CH, AKC, BKC>(acc, p.seg, m0, p.M, n0, p.N, arm, brm, it0, it1, smem);
+    mainloop<T, BM, BN, WM, WN, CH, AKC, BKC, SWAP>(acc, p.seg, m0, p.M, n0, p.N, arm, brm, it0, it1, smem);
   }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const bool first = bz == 0;
+  if constexpr (!SWAP) {
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * (TN * 16) + tn * 16 + (lane & 15);
+        if (col >= p.N) continue;
+        float add = 0.f;
+        if (first) {
+          if (p.bias) add += p.bias[col];
+          if (p.bias2) add += p.bias2[col];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * (TM * 16) + tm * 16 + (lane >> 4) * 4 + r;
+          if (row < p.M) gemm_store(p, row, col, acc[tm][tn][r] + add);
+        }
+      }
+    return;
+  }
+  // swapped MFMA roles: acc[tm][tn][r] = C[m = tm*16 + (lane & 15)][n = tn*16 + (lane >> 4)*4 + r]
+  const bool vec = (p.ldc & 3) == 0 && (p.N & 3) == 0 && (!p.C || ((uintptr_t)p.C & 15) == 0) && (!p.C2 || ((uintptr_t)p.C2 & 15) == 0) &&
+                   (!p.Clp || ((p.ldclp & 3) == 0 && ((uintptr_t)p.Clp & 7) == 0));
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = m0 + wm * (TM * 16) + tm * 16 + (lane & 15);
+    if (row >= p.M) continue;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      const int col = n0 + wn * (TN * 16) + tn * 16 + (lane & 15);
+      const int col = n0 + wn * (TN * 16) + tn * 16 + (lane >> 4) * 4;
       if (col >= p.N) continue;
-      float add = 0.f;
+      f32x4 v = acc[tm][tn];
       if (first) {
-        if (p.bias) add += p.bias[col];
-        if (p.bias2) add += p.bias2[col];
-      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * (TM * 16) + tm * 16 + (lane >> 4) * 4 + r;
-        if (row < p.M) gemm_store(p, row, col, acc[tm][tn][r] + add);
+        for (int r = 0; r < 4; ++r) {
+          if (col + r >= p.N) break;
+          float add = 0.f;
+          if (p.bias) add += p.bias[col + r];
+          if (p.bias2) add += p.bias2[col + r];
+          v[r] += add;
+        }
       }
+      gemm_store4(p, vec, row, col, v);
     }
+  }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool DMA = false>
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool DMA = false, bool SWAP = false>
 __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   using TL = Tile<T, BM, BN, WM, WN, CH>;
   // LDS-DMA main loop for interior KC/KC tiles without split-K.  A separate instantiation (it needs 128 KB of LDS for
@@ -100,13 +170,13 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
       bz = logical / (gx * gy);
     }
   }
-  gemm_tile<T, BM, BN, WM, WN, CH, AKC, BKC, DMA>(p, bx, by, bz, smem);
+  gemm_tile<T, BM, BN, WM, WN, CH, AKC, BKC, DMA, SWAP>(p, bx, by, bz, smem);
 }
 
 // Several independent problems of one shape class in ONE launch (blockIdx.z selects problem and K slice): the weight
 // gradients of a net, the two linear layers of a Gaussian head.  At small batches each of them is a latency-bound launch
 // of a few workgroups; together they fill the chip once.
-template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC>
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool SWAP = false>
 __global__ __launch_bounds__(kThreads) void gemm_group_kernel(GemmGroup g) {
   using TL = Tile<T, BM, BN, WM, WN, CH>;
   __shared__ __attribute__((aligned(16))) char smem[TL::SMEM];
@@ -115,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void gemm_group_kernel(GemmGroup g) {
   bz -= g.zbase[i];
   const GemmParams& p = g.p[i];
   if ((int)blockIdx.y * BM >= p.M || (int)blockIdx.x * BN >= p.N) return;
-  gemm_tile<T, BM, BN, WM, WN, CH, AKC, BKC, false>(p, blockIdx.x, blockIdx.y, bz, smem);
+  gemm_tile<T, BM, BN, WM, WN, CH, AKC, BKC, false, SWAP>(p, blockIdx.x, blockIdx.y, bz, smem);
 }
 
 // Scalar fallback for shapes that break the 16-byte staging preconditions (odd K / leading dimension /
@@ -151,7 +221,9 @@ static void launch_fast(const GemmParams& p, dim3 grid, hipStream_t st) {
   const int bkc = p.seg[0].K > 0 ? p.seg[0].b_kc : p.seg[1].b_kc;
   if (akc && bkc) {
     if (CH == 32 && BM == 64 && p.splitk == 1 && (int64_t)grid.x * grid.y <= 256)
-      hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, true, true, CH == 32 && BM == 64>), grid, dim3(kThreads), 0, st, p);
+      hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, true, true, CH == 32 && BM == 64, true>), grid, dim3(kThreads), 0, st, p);
+    else if (p.splitk == 1 && p.mode != 2)
+      hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, true, true, false, true>), grid, dim3(kThreads), 0, st, p);
     else
       hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 2, 2, CH, true, true>), grid, dim3(kThreads), 0, st, p);
   }
@@ -303,12 +375,18 @@ int launch_gemm_group(const GemmParams* ps, int n, int dtype, hipStream_t st) {
     gy = gy > (unsigned)fh_cdiv(p.M, 64) ? gy : (unsigned)fh_cdiv(p.M, 64);
   }
   dim3 grid(gx, gy, (unsigned)g.zbase[n]);
+  bool once = true;  // every output written once (no split-K atomics): the 16-byte-store epilogue
+  for (int i = 0; i < n; ++i) once = once && g.p[i].splitk == 1 && g.p[i].mode != 2;
   if (bf) {
-    if (akc)
+    if (akc && once)
+      hipLaunchKernelGGL((gemm_group_kernel<u16, 64, 64, 2, 2, 32, true, true, true>), grid, dim3(kThreads), 0, st, g);
+    else if (akc)
       hipLaunchKernelGGL((gemm_group_kernel<u16, 64, 64, 2, 2, 32, true, true>), grid, dim3(kThreads), 0, st, g);
     else
       hipLaunchKernelGGL((gemm_group_kernel<u16, 64, 64, 2, 2, 32, false, false>), grid, dim3(kThreads), 0, st, g);
-  } else if (akc && bkc)
+  } else if (akc && bkc && once)
+    hipLaunchKernelGGL((gemm_group_kernel<float, 64, 64, 2, 2, 32, true, true, true>), grid, dim3(kThreads), 0, st, g);
+  else if (akc && bkc)
     hipLaunchKernelGGL((gemm_group_kernel<float, 64, 64, 2, 2, 32, true, true>), grid, dim3(kThreads), 0, st, g);
   else if (!akc && !bkc)
     hipLaunchKernelGGL((gemm_group_kernel<float, 64, 64, 2, 2, 32, false, false>), grid, dim3(kThreads), 0, st, g);

@@ -203,7 +203,9 @@ __host__ inline bool seg_fast_ok(const Seg& s, int M, int N) {
 // The main loop.  Panels of both segments are numbered consecutively; [it_begin, it_end) selects a
 // sub-range (split-K).  smem must hold Tile::SMEM bytes (16-byte aligned).  AKC/BKC: operand orientation
 // (compile time; both segments share it).  bf16 supports KC/KC and KM/KM only.
-template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, class ARowMap, class BRowMap>
+// SWAP: the B fragment is the first MFMA operand, so a lane holds 4 consecutive COLUMNS (n) of one row (m = lane & 15) instead
+// of 4 consecutive rows of one column: row-major outputs then leave as 16-byte stores (gemm_tile's epilogue)
+template <typename T, int BM, int BN, int WM, int WN, int CH, bool AKC, bool BKC, bool SWAP, class ARowMap, class BRowMap>
 __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const Seg (&segs)[2], int m0, int M,
                                          int n0, int N, const ARowMap& arm, const BRowMap& brm, int it_begin,
                                          int it_end, char* smem) {
@@ -290,7 +292,8 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
           for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(b[tn][s], a[tm][s], acc[tm][tn], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
       } else {
         bf16x8 a[TM], b[TN];
         if constexpr (AKC) {
@@ -314,7 +317,8 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[BM / WM / 16][BN / WN / 16
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tn], a[tm], acc[tm][tn], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -368,7 +372,7 @@ struct GldsTile {
 };
 
 // whole contraction (no split-K) of an interior KC/KC tile
-template <typename T, int BM, int BN, int WM, int WN, int CH, int NBUF, class ARowMap, class BRowMap>
+template <typename T, int BM, int BN, int WM, int WN, int CH, int NBUF, bool SWAP, class ARowMap, class BRowMap>
 __device__ __forceinline__ void mainloop_glds(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const Seg (&segs)[2], int m0, int n0,
                                               const ARowMap& arm, const BRowMap& brm, char* smem) {
   using GT = GldsTile<T, BM, BN, WM, WN, CH, NBUF>;
@@ -414,7 +418,8 @@ __device__ __forceinline__ void mainloop_glds(f32x4 (&acc)[BM / WM / 16][BN / WN
           for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(b[tn][s], a[tm][s], acc[tm][tn], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
       } else {
         bf16x8 a[TM], b[TN];
 #pragma unroll
@@ -427,7 +432,8 @@ __device__ __forceinline__ void mainloop_glds(f32x4 (&acc)[BM / WM / 16][BN / WN
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tn], a[tm], acc[tm][tn], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
     }
     if (NBUF == 1 && p + 1 < nkb) {

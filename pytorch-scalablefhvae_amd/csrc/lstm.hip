@@ -130,9 +130,9 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
   const bool dma = jobs.glds && m0 + BM <= B && brm.all_valid(n0, BN) && seg_glds_ok<T>(J.seg[0], TL::BK) &&
                    seg_glds_ok<T>(J.seg[1], TL::BK);
   if (dma)
-    mainloop_glds<T, BM, BN, WM, WN, CH, NBUF>(acc, J.seg, m0, n0, arm, brm, smem);
+    mainloop_glds<T, BM, BN, WM, WN, CH, NBUF, false>(acc, J.seg, m0, n0, arm, brm, smem);
   else
-    mainloop<T, BM, BN, WM, WN, CH, true, true>(acc, J.seg, m0, B, n0, (int)gridDim.y * BN, arm, brm, 0, nkb, smem);
+    mainloop<T, BM, BN, WM, WN, CH, true, true, false>(acc, J.seg, m0, B, n0, (int)gridDim.y * BN, arm, brm, 0, nkb, smem);
 
   if (!uok) return;
 #pragma unroll
@@ -215,9 +215,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
   if constexpr (sizeof(T) == 2)
     dma = jobs.glds && m0 + BM <= B && n0 + BN <= H && seg_glds_ok<T>(J.seg[0], TL::BK) && seg_glds_ok<T>(J.seg[1], TL::BK);
   if (dma) {
-    if constexpr (sizeof(T) == 2) mainloop_glds<T, BM, BN, WM, WN, CH, NBUF>(acc, J.seg, m0, n0, arm, brm, smem);
+    if constexpr (sizeof(T) == 2) mainloop_glds<T, BM, BN, WM, WN, CH, NBUF, false>(acc, J.seg, m0, n0, arm, brm, smem);
   } else {
-    mainloop<T, BM, BN, WM, WN, CH, true, sizeof(T) == 2>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
+    mainloop<T, BM, BN, WM, WN, CH, true, sizeof(T) == 2, false>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
   }
 
 #pragma unroll
