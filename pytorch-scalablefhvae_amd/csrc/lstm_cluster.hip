@@ -615,6 +615,10 @@ struct ClBwd {
   u16* xch;  // exchange buffer (blocked copy of dg; contraction-split form)
   unsigned* sync;
   unsigned long long* tlog;
+  // contraction-split per-layer kernel, layer below the top: the from-above term dg^{l+1}_t . W_ih[l+1] is computed by the launch
+  // itself from the finished layer above (row-major dg, (T,B,4H)) instead of being handed in through d_hs_top
+  const u16* dg_above;
+  const u16* w_above_t;  // W_ih[l+1]^T, [H,4H] bf16
 };
 
 template <int H, int L, int RB>
@@ -1530,14 +1534,27 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
 // contiguous), the partial tiles are summed through LDS, wave w finishes unit tile w.  Epilogue operands are fetched one step
 // ahead (as in lstm_bwd_ksplit_kernel).
 // ---------------------------------------------------------------------------------------------
-template <int H, int RT>
+// ABOVE (a layer below the top): the from-above term dg^{l+1}_t . W_ih[l+1] is computed HERE, from the finished layer above
+// (row-major dg, fetched a step ahead) against W_ih[l+1]^T held in the 128 KB of LDS this kernel no longer needs for its own
+// weights.  It is a K-split partial sum over the same unit tiles as the recurrent product, so it simply starts the accumulators
+// -- and it does not depend on the exchange, so its 64 MFMAs per wave run BEFORE the flag wait, in time that was idle.  The
+// (T*B x 4H x H) GEMM between the two launches of a net and its f32 (T,B,H) round trip are gone.
+template <int H, int RT, bool ABOVE>
 __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
   constexpr int HU = 64, UT = 4;
-  constexpr int G = 4 * H, KS = G / 32, KPW = KS / 4;
+  constexpr int G = 4 * H, GC = G / 8, KB = GC / 64, KS = G / 32, KPW = KS / 4;
+  constexpr int WU_BYTES = ABOVE ? HU * GC * 16 : 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Part = smem;                       // [wave][RT][UT] tiles of 1 KB
-  char* Stg = smem + 4 * RT * UT * 1024;   // dg of this step, [RT * 16 rows][4 gates][64 units] bf16 (row stride kStgRow)
+  char* Wu = smem;                                    // ABOVE: this member's 64 rows of W_ih[l+1]^T
+  char* Part = smem + WU_BYTES;                       // [wave][RT][UT] tiles of 1 KB
+  char* Stg = smem + WU_BYTES + 4 * RT * UT * 1024;   // !ABOVE: dg of this step, [RT * 16 rows][4 gates][64 units] bf16
   constexpr int kStgRow = 4 * HU * 2 + 16;
+  // ABOVE: no LDS is left for that image; wave w keeps its 32 bytes per (row, gate) in the partial tiles only IT reads (k = 0, 1
+  // of unit tile w), written after it has read them; a barrier in front of the next step's partial-tile writes protects it
+  auto stg_alias = [&](int wsrc, int rt, int row16, int g, int byte) -> char* {
+    const int off = (row16 * 4 + g) * 32 + byte;  // 2 KB per (wave, row tile)
+    return Part + (((off >> 10) * RT + rt) * UT + wsrc) * 1024 + (off & 1023);
+  };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int kp = wave;
@@ -1562,6 +1579,11 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
     for (int ut = 0; ut < UT; ++ut)
       wreg[j][ut] = __builtin_bit_cast(bf16x8, *(const uint4*)(p.w_hh_t[0] + (int64_t)(u0 + ut * 16 + r) * G + ((((kp * KPW + j) << 2) | q) << 3)));
+  if constexpr (ABOVE) {
+    ClUnitMap um{u0};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) glds_tile<u16, HU, 64>(Wu + kb * (HU * 1024), p.w_above_t, G, 0, kb * 512, um, 0, tid);
+  }
   int row[RT];
   int64_t rowc[RT];
 #pragma unroll
@@ -1601,6 +1623,20 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
     }
   };
   load_epi(0);
+  // ABOVE: this wave's k-steps of dg^{l+1}_t (row-major), fetched one step ahead like the epilogue operands
+  uint4 a2n[RT][ABOVE ? KPW : 1];
+  auto load_above = [&](int t) {
+    if constexpr (ABOVE) {
+      const int tc = t > 0 ? t : 0;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const u16* src = p.dg_above + ((int64_t)tc * B + rowc[rt]) * G + (((kp * KPW) << 2) | q) * 8;
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) a2n[rt][j] = *(const uint4*)(src + j * 32);
+      }
+    }
+  };
+  load_above(T - 1);
   for (int s = 0; s < T; ++s) {
     CL_TLOG(s * 8 + 0);
     const int t = T - 1 - s;
@@ -1614,14 +1650,32 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
       ext[rt] = extn[rt];
       if (s == 0) ccur[rt] = ccurn[rt];
     }
-    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
-    CL_TLOG(s * 8 + 1);
-
     f32x4 acc[RT][UT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int ut = 0; ut < UT; ++ut) acc[rt][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (ABOVE) {  // the from-above term of time t: before the wait (it does not depend on the exchange)
+      bf16x8 wu[2][UT];
+      auto ufrags = [&](int j, int buf) {
+        const int kc = ((kp * KPW + j) << 2) | q;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+          wu[buf][ut] = __builtin_bit_cast(bf16x8, *(const uint4*)(Wu + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
+      };
+      ufrags(0, 0);
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) {
+        if (j + 1 < KPW) ufrags(j + 1, (j + 1) & 1);
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[j & 1][ut], __builtin_bit_cast(bf16x8, a2n[rt][j]), acc[rt][ut], 0, 0, 0);
+      }
+    }
+    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
+    CL_TLOG(s * 8 + 1);
     if (s > 0) {
       uint4 a[RT][KPW];
 #pragma unroll
@@ -1630,6 +1684,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
         for (int j = 0; j < KPW; ++j) a[rt][j] = load_sc1(dg_rs, base + j * (B * 64));
       }
+      if constexpr (ABOVE) load_above(t - 1);  // behind the exchange loads: lands during the epilogue
       __builtin_amdgcn_sched_barrier(0);  // every exchange load is in flight before the first MFMA (the scheduler sinks them otherwise)
 #pragma unroll
       for (int j = 0; j < KPW; ++j)
@@ -1638,7 +1693,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
             acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][ut], __builtin_bit_cast(bf16x8, a[rt][j]), acc[rt][ut], 0, 0, 0);
+    } else if constexpr (ABOVE) {
+      load_above(t - 1);
     }
+    if constexpr (ABOVE) __syncthreads();  // every wave has read the dg image of the previous step out of the partial tiles
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -1673,7 +1731,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
           dgs[rt][g] += dp[g];
           dpk[rt][g] = pack4(dp[g]);
           *(uint2*)(p.xch + xch_off(s & 1, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];  // what the members wait for
-          *(uint2*)(Stg + (rt * 16 + r) * kStgRow + g * (HU * 2) + (wave * 16 + q * 4) * 2) = dpk[rt][g];
+          if constexpr (ABOVE)
+            *(uint2*)stg_alias(wave, rt, r, g, q * 8) = dpk[rt][g];
+          else
+            *(uint2*)(Stg + (rt * 16 + r) * kStgRow + g * (HU * 2) + (wave * 16 + q * 4) * 2) = dpk[rt][g];
         }
       }
     }
@@ -1688,7 +1749,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
       for (int i = 0; i < RT * 2; ++i) {
         const int c = (wave * RT * 2 + i) * 64 + lane, idx = c >> 3;  // 16-byte chunk c of the image: (row, gate) idx, chunk c & 7
-        v[i] = *(const uint4*)(Stg + (idx >> 2) * kStgRow + (idx & 3) * (HU * 2) + (c & 7) * 16);
+        if constexpr (ABOVE)
+          v[i] = *(const uint4*)stg_alias((c & 7) >> 1, idx >> 6, (idx >> 2) & 15, idx & 3, (c & 1) * 16);
+        else
+          v[i] = *(const uint4*)(Stg + (idx >> 2) * kStgRow + (idx & 3) * (HU * 2) + (c & 7) * 16);
       }
 #pragma unroll
       for (int i = 0; i < RT * 2; ++i) {
@@ -1916,17 +1980,21 @@ static int launch_bwd_layer_rb(const ClBwd& p, int RB, hipStream_t st) {
   }
 }
 
-template <int RT>
-static int launch_bwd_layer_ks(const ClBwd& p, hipStream_t st) {
-  constexpr int SMEM = 4 * RT * 4 * 1024 + RT * 16 * (4 * 64 * 2 + 16);
+template <int RT, bool ABOVE>
+static int launch_bwd_layer_ks_a(const ClBwd& p, hipStream_t st) {
+  constexpr int SMEM = ABOVE ? 64 * (4 * 256 / 8) * 16 + 4 * RT * 4 * 1024 : 4 * RT * 4 * 1024 + RT * 16 * (4 * 64 * 2 + 16);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_ks_kernel<256, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_ks_kernel<256, RT, ABOVE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL((lstm_bwd_layer_ks_kernel<256, RT>), dim3(kGrid), dim3(kThreads), SMEM, st, p);
+  hipLaunchKernelGGL((lstm_bwd_layer_ks_kernel<256, RT, ABOVE>), dim3(kGrid), dim3(kThreads), SMEM, st, p);
   return fh_launch_status();
+}
+template <int RT>
+static int launch_bwd_layer_ks(const ClBwd& p, hipStream_t st) {
+  return p.dg_above ? launch_bwd_layer_ks_a<RT, true>(p, st) : launch_bwd_layer_ks_a<RT, false>(p, st);
 }
 
 // rows form, layer by layer (see lstm_bwd_layer_kernel): top layer first, then the from-above contraction as one GEMM into
@@ -1938,6 +2006,8 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
   // (measured: B = 1024: 544k vs 515k segments/s, 2048: 743k vs 728k; from 4096 rows on the 32-unit kernel with 128 rows per
   //  cluster wins, 868k vs 833k: the contraction-split launch holds 2048 rows)
   const bool ks = H == 256 && d->B <= 2048 && !getenv("FHVAE_NO_LAYER_KS");
+  // contraction-split form: a layer below the top computes the from-above term itself (no GEMM, no ws_below round trip)
+  const bool fuse_above = ks && !getenv("FHVAE_NO_FUSE_ABOVE");
   const int HU = ks ? 64 : 32;
   const int NU = H / HU, NC = kGrid / NU;
   const int64_t B = d->B, T = d->T, G = 4 * H;
@@ -1959,7 +2029,11 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.w_hh_t[0] = w.w_hh_t[l];
       p.gates = (const u16*)d->gates + (int64_t)l * T * B * G;
       p.cs = d->cs + (int64_t)l * T * B * H;
-      p.d_hs_top = l == L - 1 ? bd->d_hs_top : bd->ws_below;
+      p.d_hs_top = l == L - 1 ? bd->d_hs_top : (fuse_above ? nullptr : bd->ws_below);
+      if (fuse_above && l < L - 1) {
+        p.dg_above = (const u16*)bd->dgates + (int64_t)(l + 1) * T * B * G;
+        p.w_above_t = w.w_ih_t[l + 1];
+      }
       p.d_hn = bd->d_hn ? bd->d_hn + (int64_t)l * H : nullptr;
       p.hn_ld = L * H;
       p.dg = (u16*)bd->dgates + (int64_t)l * T * B * G;
@@ -1968,14 +2042,14 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.db_hh[0] = bd->db_hh[l];
       p.sync = (unsigned*)d->lp;
       p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
-      const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * (T - 1) * 4.0 * H);
+      const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * ((T - 1) + (p.dg_above ? T : 0)) * 4.0 * H);
       p.xch = w.xch;
       const int e = ks ? (RB <= 16 ? launch_bwd_layer_ks<1>(p, st) : launch_bwd_layer_ks<2>(p, st))
                        : (H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st));
       trace_end(st, ts);
       if (e) return e;
     }
-    if (l > 0) {  // ws_below[T*B, H] = dg^l [T*B, 4H] . W_ih[l]  (its transposed bf16 copy [H,4H] as the KC operand)
+    if (l > 0 && !fuse_above) {  // ws_below[T*B, H] = dg^l [T*B, 4H] . W_ih[l]  (its transposed bf16 copy [H,4H] as the KC operand)
       GemmParams g = {};
       g.seg[0] = Seg{(const u16*)bd->dgates + (int64_t)l * T * B * G, G, 1, w.w_ih_t[l], G, 1, (int)G, 0};
       g.M = (int)(T * B);
