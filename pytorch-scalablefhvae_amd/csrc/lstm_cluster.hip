@@ -1664,6 +1664,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
           wu[buf][ut] = __builtin_bit_cast(bf16x8, *(const uint4*)(Wu + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
       };
       ufrags(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, UT, 0);
 #pragma unroll
       for (int j = 0; j < KPW; ++j) {
         if (j + 1 < KPW) ufrags(j + 1, (j + 1) & 1);
@@ -1672,6 +1673,13 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
             acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[j & 1][ut], __builtin_bit_cast(bf16x8, a2n[rt][j]), acc[rt][ut], 0, 0, 0);
+        if (j + 1 < KPW) {  // the next k-step's four fragment reads go out behind this one's first MFMA
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, UT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, RT * UT - 1, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, RT * UT, 0);
+        }
       }
     }
     if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
@@ -1684,7 +1692,6 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
         for (int j = 0; j < KPW; ++j) a[rt][j] = load_sc1(dg_rs, base + j * (B * 64));
       }
-      if constexpr (ABOVE) load_above(t - 1);  // behind the exchange loads: lands during the epilogue
       __builtin_amdgcn_sched_barrier(0);  // every exchange load is in flight before the first MFMA (the scheduler sinks them otherwise)
 #pragma unroll
       for (int j = 0; j < KPW; ++j)
@@ -1693,8 +1700,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
             acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][ut], __builtin_bit_cast(bf16x8, a[rt][j]), acc[rt][ut], 0, 0, 0);
-    } else if constexpr (ABOVE) {
-      load_above(t - 1);
+    }
+    if constexpr (ABOVE) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_above(t - 1);  // behind the exchange loads and their MFMAs: lands during the epilogue
     }
     if constexpr (ABOVE) __syncthreads();  // every wave has read the dg image of the previous step out of the partial tiles
 #pragma unroll
