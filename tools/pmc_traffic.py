@@ -45,8 +45,9 @@ def main():
         w = [(k, v) for k, v in wr.items() if short in k and (tname in k or not typed)]
         if not f or not w:
             continue
-        fn, fv = f[0][1]
-        wn, wv = w[0][1]
+        # every instantiation of the kernel (e.g. the per-layer backward with and without the fused from-above term) counts
+        fn, fv = sum(v[0] for _, v in f), sum(v[1] for _, v in f)
+        wn, wv = sum(v[0] for _, v in w), sum(v[1] for _, v in w)
         rd = 2.0 * fv / fn * 1024.0   # FETCH_SIZE in KiB, x2 gfx950 correction for wide coalesced reads
         wb = wv / wn * 1024.0
         res["%s_%s_B%d" % (short, dtype, B)] = {"hbm_bytes_per_launch": rd + wb, "read_bytes": rd, "write_bytes": wb,
