@@ -111,3 +111,34 @@ def test_no_cluster_env_forces_step_kernels(hb):
         assert hb.LAST_LSTM_FORM["form"] == 0
     finally:
         os.environ.pop("FHVAE_NO_CLUSTER", None)
+
+
+@pytest.mark.parametrize("B,T,Ic", [(1024, 6, 0), (1100, 4, 32), (2048, 20, 0)])
+def test_from_above_term_fused_or_by_gemm(hb, B, T, Ic):
+    """Per-layer backward (contraction-split form, H = 256): the lower layer's launch computes dg^{l+1}.W_ih^{l+1} itself
+    (default) or takes it from the GEMM between the launches (FHVAE_NO_FUSE_ABOVE=1): same products, a different order of
+    the f32 partial sums, so the two agree far inside the bf16 tolerance; ragged clusters and the time-constant input too."""
+    I, H, L = 80, 256, 2
+    torch.manual_seed(B + T)
+    lstm = torch.nn.LSTM(I + Ic, H, L)
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    params = [getattr(lstm, n).detach().cuda() for n in names]
+    x = torch.randn(T, B, I).cuda()
+    xc = torch.randn(B, Ic).cuda() if Ic else None
+    g_out, g_hn = torch.randn(T, B, H).cuda(), torch.randn(B, L * H).cuda()
+    try:
+        os.environ.pop("FHVAE_NO_FUSE_ABOVE", None)
+        a = _run(hb, x, xc, T, params, g_out, g_hn, True)
+        assert hb.LAST_LSTM_FORM["form"] == 1 and hb.lstm_sync_status() == 0
+        os.environ["FHVAE_NO_FUSE_ABOVE"] = "1"
+        b = _run(hb, x, xc, T, params, g_out, g_hn, True)
+        assert hb.lstm_sync_status() == 0
+    finally:
+        os.environ.pop("FHVAE_NO_FUSE_ABOVE", None)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])  # the forward is the same launch
+    for ga, gb, n in zip(a[2], b[2], names):
+        err = (ga - gb).abs().max().item()
+        assert err <= 2e-3 * gb.abs().max().item() + 1e-6, (n, err, gb.abs().max().item())
+    if Ic:
+        err = (a[3] - b[3]).abs().max().item()
+        assert err <= 2e-3 * b[3].abs().max().item() + 1e-6, ("d_xc", err)
