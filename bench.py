@@ -234,7 +234,7 @@ def main():
         if form == 1 and not os.environ.get("FHVAE_NO_LAYERWISE"):
             # rows form: the backward runs one persistent launch per layer (contraction-split variant up to 2048 rows at
             # H = 256: the library's rule in cluster_bwd_layers)
-            names[1] = "lstm_bwd_layer_ks_kernel" if (H == 256 and B <= 2048) else "lstm_bwd_layer_kernel"
+            names[1] = "lstm_bwd_layer_ks_kernel" if H == 256 else "lstm_bwd_layer_kernel"
         if not cells:  # FC model: no LSTM cells to trace
             cells = {0: (1, 1e-9, 0.0)}
         dom = max(cells, key=lambda k: cells[k][1])

@@ -167,7 +167,7 @@ typedef struct fhvae_lstm_bwd_desc {
                      second stream, under the next net's latency-bound recurrence */
   float* ws_below; /* (T,B,H) f32 workspace, required when fhvae_lstm_form(&f) == 1 and L > 1: the persistent backward runs
                       layer by layer and hands the from-above gradient dg^{l+1}.W_ih^{l+1} to the lower layer through it
-                      (H = 256 and B <= 2048: the lower layer's launch computes that term itself and leaves it untouched) */
+                      (H = 256: the lower layer's launch computes that term itself and leaves it untouched) */
 } fhvae_lstm_bwd_desc;
 
 int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* d, void* stream);

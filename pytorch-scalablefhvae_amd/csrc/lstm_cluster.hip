@@ -2011,10 +2011,11 @@ static int launch_bwd_layer_ks(const ClBwd& p, hipStream_t st) {
 static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;
   const int H = (int)d->H, L = d->L;
-  // H = 256: 64 units per member with the waves splitting K (2048 rows per launch); else 32 units per member, waves split rows
-  // (measured: B = 1024: 544k vs 515k segments/s, 2048: 743k vs 728k; from 4096 rows on the 32-unit kernel with 128 rows per
-  //  cluster wins, 868k vs 833k: the contraction-split launch holds 2048 rows)
-  const bool ks = H == 256 && d->B <= 2048 && !getenv("FHVAE_NO_LAYER_KS");
+  // H = 256: 64 units per member with the waves splitting K (2048 rows per launch, larger batches as consecutive launches);
+  // else 32 units per member, waves split rows.  (Before the contraction-split kernel's weights became register-stationary and
+  // it took over the from-above term, the 32-unit kernel with 128 rows per cluster won from 4096 rows on; now B = 3072:
+  // 864k vs 818k segments/s, 4096: 947k vs 924k, 8192: 999k vs 985k.)
+  const bool ks = H == 256 && !getenv("FHVAE_NO_LAYER_KS");
   // contraction-split form: a layer below the top computes the from-above term itself (no GEMM, no ws_below round trip)
   const bool fuse_above = ks && !getenv("FHVAE_NO_FUSE_ABOVE");
   const int HU = ks ? 64 : 32;
