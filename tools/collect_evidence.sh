@@ -11,6 +11,6 @@ for c in c3 c4 c5; do
   python3 $R/bench.py --config $c --no-cpu-baseline --steps 10 --warmup 3 > $R/gpurun_out/ev/bench_$c.json 2> $R/gpurun_out/ev/bench_$c.log
   rocprofv3 --kernel-trace -d /tmp/kt_$c -o r -- python3 $R/bench.py --config $c --no-cpu-baseline --no-roofline --no-graph --steps 10 --warmup 3 > $R/gpurun_out/ev/prof_$c.log 2>&1
   db=$(find /tmp/kt_$c -name "*.db" | head -1)
-  python3 $R/tools/rocpd_stats.py $db 13 > $R/gpurun_out/ev/${c}_kernel_stats.txt
+  { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py ... --no-graph --steps 10 --warmup 3 (per-kernel totals via tools/rocpd_stats.py; 13 steps traced, times per step)"; python3 $R/tools/rocpd_stats.py $db 13; } > $R/gpurun_out/ev/${c}_kernel_stats.txt
   echo done $c
 done
