@@ -444,12 +444,13 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
   const T* w0 = op.w_ih[0];
   // ---- layer-0 input projection (+ both biases): pre = [x_t || xc] . W_ih0^T + b_ih0 + b_hh0.  The persistent kernels
   //      multiply x_t themselves when they can (fold): then only the time-constant part is left for this GEMM
-  bool cluster = false, fold = false;
+  bool cluster = false, fold = false, xc_in = false;
   if constexpr (sizeof(T) == 2) {
     cluster = cluster_eligible(d);
     fold = cluster && cluster_can_fold(d);
+    xc_in = cluster && cluster_xc_in_kernel(d);
   }
-  if (!(fold && Ic == 0)) {
+  if (!(fold && Ic == 0) && !xc_in) {
     GemmParams p = {};
     int s = 0;
     if (I > 0 && !fold) p.seg[s++] = Seg{op.x, I, 1, w0, K0, 1, (int)I, 0};
@@ -470,6 +471,7 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
       for (int l = 0; l < L; ++l) cw.w_ih[l] = op.w_ih[l], cw.w_hh[l] = op.w_hh[l], cw.w_ih_t[l] = op.w_ih_t[l], cw.w_hh_t[l] = op.w_hh_t[l];
       cw.xch = (u16*)d->lp + lp_layout(d).xch;
       cw.x_fold = fold ? (const u16*)op.x : nullptr;
+      cw.xc_fold = xc_in ? (const u16*)op.xc : nullptr;
       return cluster_fwd(d, cw, st);
     }
   }

@@ -22,6 +22,7 @@ struct ClusterWeights {  // bf16 operand copies in the workspace
   const u16* w_hh_t[FHVAE_MAX_LAYERS];  // [H, 4H]
   u16* xch;                             // exchange buffer: 2 * L * B * 4H bf16 (lstm_cluster.hip, xch_off)
   const u16* x_fold;                    // (T,B,I) bf16 when the forward kernels do the layer-0 input projection themselves
+  const u16* xc_fold;                   // (B,Ic) bf16 when the rows-form forward kernel projects the time-constant input itself
 };
 
 // whether this device / shape can run the cluster kernels (gfx950 with 256 CUs, bf16, H in {128, 256}, L <= 2, ...)
@@ -30,6 +31,7 @@ bool cluster_eligible(const fhvae_lstm_desc* d);
 int cluster_form(const fhvae_lstm_desc* d);
 // the forward kernels can multiply x_t by W_ih[0][:, :I] themselves (I a multiple of 8, at most 128, rows 16-byte aligned)
 bool cluster_can_fold(const fhvae_lstm_desc* d);
+bool cluster_xc_in_kernel(const fhvae_lstm_desc* d);
 // the recurrence of fhvae_lstm_seq_fwd after the layer-0 input projection (d->pre filled): all T steps, all layers
 int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st);
 // the recurrence of fhvae_lstm_seq_bwd: fills dgates (and dgsum when Ic > 0)

@@ -203,6 +203,10 @@ struct ClFwd {
   unsigned* sync;
   unsigned long long* tlog;  // optional phase clock log of cluster 0 / member 0 (tools/prof_cluster.py)
   int il;                    // rows form, L = 2: layer 0's gate math between the MFMAs of the h^1 panels
+  // rows form: the time-constant input xc (B,Ic) bf16 is projected by the kernel itself, once, into layer 0's additive term
+  // (W_ih[0][:, I:I+Ic] from w_ih0); `pre` is then NULL and no GEMM runs before the launch
+  const u16* xcv;
+  int Ic;
 };
 
 template <int H, int L, int RB>
@@ -316,6 +320,36 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     }
   };
   load_pre(0);
+  if (p.xcv) {  // the time-constant input's projection, once: same fragment roles as the folded x projection below
+    const int nkc = (p.Ic + 31) / 32, nchc = p.Ic / 8;
+    f32x4 accx[TM][4];
+    zero_acc(accx);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // Ic <= 128
+      if (j >= nkc) break;
+      const int c = j * 4 + q;
+      const bool ok = c < nchc;
+      uint4 xf[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = r0 + wrow0 + tm * 16 + r;
+        xf[tm] = uint4{0u, 0u, 0u, 0u};
+        if (ok && wact) xf[tm] = *(const uint4*)(p.xcv + (int64_t)(row < rend ? row : rend - 1) * p.Ic + c * 8);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint4 wf = uint4{0u, 0u, 0u, 0u};
+        if (ok) wf = *(const uint4*)(p.w_ih0 + (int64_t)(g * H + u0 + r) * p.K0 + p.I + c * 8);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          accx[tm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf[tm]), accx[tm][g], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pnext[tm][g] += accx[tm][g];
+  }
   // folded input projection: this member's W_ih[0] fragments (gate g, k-step j) stay in registers for the whole launch;
   // the x fragments of step s+1 are fetched under the epilogue of step s (x comes from HBM, like `pre`)
   constexpr int KSX = 4;  // up to 128 input features
@@ -1851,6 +1885,21 @@ static void cluster_rows(int64_t nrows, int NC, int* Mc, int* RB) {
   *RB = m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : 128;
 }
 
+// rows form: the forward kernel projects the time-constant input itself (no GEMM, no (B,4H) f32 round trip)
+bool cluster_xc_in_kernel(const fhvae_lstm_desc* d) {
+  if (!(d->Ic > 0 && d->Ic % 8 == 0 && d->Ic <= 128 && d->I % 8 == 0 && (d->I == 0 || cluster_can_fold(d))) || getenv("FHVAE_NO_XC_FOLD"))
+    return false;
+  // every launch of the forward (batches beyond one launch run as consecutive row chunks) has to take the rows kernel
+  const int NC = kGrid / ((int)d->H / 16);
+  const int64_t chunk = (int64_t)NC * 128;
+  for (int64_t row0 = 0; row0 < d->B; row0 += chunk) {
+    int Mc, RB;
+    cluster_rows(d->B - row0 < chunk ? d->B - row0 : chunk, NC, &Mc, &RB);
+    if (RB <= 32) return false;
+  }
+  return true;
+}
+
 bool cluster_can_fold(const fhvae_lstm_desc* d) {
   return d->I > 0 && d->I % 8 == 0 && d->I <= 128 && (d->I + d->Ic) % 8 == 0 && !getenv("FHVAE_NO_FOLD");
 }
@@ -1893,6 +1942,15 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     } else {
       p.pre = d->pre;
       p.pre_tstride = d->I > 0 ? d->B * 4 * d->H : 0;
+    }
+    if (w.xc_fold) {  // (rows form only, cluster_xc_in_kernel) nothing was left in d->pre: the kernel projects xc itself
+      p.xcv = w.xc_fold;
+      p.Ic = (int)d->Ic;
+      p.w_ih0 = w.w_ih[0];
+      p.I = (int)d->I;
+      p.K0 = (int)(d->I + d->Ic);
+      p.pre = nullptr;
+      p.pre_tstride = 0;
     }
     p.hs = (u16*)d->hs;
     p.cs = d->cs;

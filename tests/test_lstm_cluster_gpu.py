@@ -42,7 +42,9 @@ def _run(hb, x_tm, xc, T, params, g_out, g_hn, cluster):
 CASES = [(256, 20, 80, 0, 256, 2), (100, 7, 80, 32, 256, 2), (16, 5, 0, 64, 256, 2), (5, 3, 80, 0, 256, 2),
          (2048, 20, 80, 0, 256, 2), (300, 6, 40, 0, 128, 2), (64, 4, 80, 0, 256, 1), (2500, 3, 80, 32, 256, 2),
          (700, 1, 80, 0, 256, 2), (1000, 9, 0, 64, 128, 1), (1024, 5, 80, 0, 256, 2), (1500, 4, 80, 32, 128, 2),
-         (4100, 2, 0, 64, 256, 1)]
+         (4100, 2, 0, 64, 256, 1),
+         # rows form with a time-constant input: projected inside the forward kernel (with and without a per-frame input)
+         (2048, 3, 80, 32, 256, 2), (1024, 4, 0, 64, 256, 2)]
 
 
 @pytest.mark.parametrize("B,T,I,Ic,H,L", CASES)
