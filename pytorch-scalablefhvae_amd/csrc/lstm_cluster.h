@@ -5,14 +5,15 @@
 namespace fh {
 
 // The first FHVAE_LSTM_SYNC_BYTES of the bf16 workspace (fhvae_lstm_desc.lp) are the kernels' sync block (u32 words):
-constexpr int kSyncStatus = 0;    // 0 = ok; bit 0: a bounded spin gave up, bit 1: an XCD received more than 32 workgroups
-constexpr int kSyncXcdCnt = 16;   // 8 arrival counters (one per XCD): a workgroup's slot on its XCD
+constexpr int kSyncStatus = 0;    // 0 = ok; bit 0: a bounded spin gave up, bit 1: a workgroup could not read its XCD
+constexpr int kSyncXcdCnt = 16;   // 8 arrival counters (one per XCD): ticket & 31 = a workgroup's slot on its XCD, ticket >> 5 = the launch
 constexpr int kSyncFlags = 64;    // + cluster * 32: one word per workgroup of the cluster = the last step it has published
 constexpr int kSyncWordsUsed = kSyncFlags + 64 * 32;
-// The block is zeroed once per forward (by the operand-cast launch that precedes every bf16 forward); the launches that
-// then share it -- forward chunks, later the backward's -- are numbered 0, 1, ... (`seq`, a constant of the call, so it
-// survives graph replay): launch `seq` owns the tickets [32 seq, 32 seq + 32) of every XCD counter and the flag epochs
-// (seq * kSeqEpochs, (seq + 1) * kSeqEpochs].
+// The block is zeroed once per forward (by the operand-cast launch that precedes every bf16 forward); the launches that then
+// share it -- forward chunks, later the backward's, however often it runs -- number themselves: every launch takes 32 tickets
+// of each XCD counter, so launch n holds the tickets [32 n, 32 n + 32) and uses the flag epochs (n * kSeqEpochs, (n + 1) *
+// kSeqEpochs].  Nothing is re-armed between the launches (and nothing depends on the host counting them: graph replay repeats
+// the same sequence from the same zeroed block).
 constexpr int kSeqEpochs = 4096;
 
 struct ClusterWeights {  // bf16 operand copies in the workspace

@@ -55,14 +55,18 @@ __device__ __forceinline__ unsigned xcc_id() {
   return v & 0xf;
 }
 
-// slot of this workgroup on its XCD: x * 32 + slot, or -1 (abort)
-__device__ __forceinline__ int cluster_join(unsigned* sync, int seq, int* s_word) {
+// Slot of this workgroup on its XCD and the number of this launch on the sync block: (launch << 8) | (x * 32 + slot), or -1
+// (abort).  An XCD's counter hands out 32 tickets per launch (256 workgroups, 32 per XCD), so ticket / 32 IS the launch number:
+// the host does not have to count launches, and the backward needs no re-arming of the block after the forward.  (If an XCD ever
+// received a 33rd workgroup of one launch it would take a ticket of the next launch and wait for flags nobody raises: the bounded
+// spin ends the launch with the status word set.)
+__device__ __forceinline__ int cluster_join(unsigned* sync, int* s_word) {
   if (threadIdx.x == 0) {
     const unsigned x = xcc_id();
     int v = -1;
     if (x < 8) {
-      const unsigned slot = __hip_atomic_fetch_add(sync + kSyncXcdCnt + x, 1u, RLX_AGENT) - 32u * (unsigned)seq;
-      if (slot < 32) v = (int)(x * 32 + slot);
+      const unsigned ticket = __hip_atomic_fetch_add(sync + kSyncXcdCnt + x, 1u, RLX_AGENT);
+      v = (int)(((ticket >> 5) << 8) | (x * 32 + (ticket & 31u)));
     }
     if (v < 0) __hip_atomic_fetch_or(sync + kSyncStatus, 2u, RLX_AGENT);
     s_word[0] = v;
@@ -182,7 +186,6 @@ __device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, int64_t byt
 struct ClFwd {
   int B, T, NU, Mc;    // B: row count of the (T,B,.) buffers; NU workgroups per cluster; Mc rows per cluster
   int row0, nrows;     // rows handled by this launch
-  int seq;             // number of this launch on the workspace's sync block (lstm_cluster.h)
   const u16* w_ih[2];  // [4H,H] bf16 (l = 1)
   const u16* w_hh[2];
   const float* b_ih[2];
@@ -232,9 +235,10 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
   char* ring = smem + CF::NW * CF::W_BYTES + wave * (kRing * kPanel);  // this wave's staging ring
   const int r = lane & 15, q = lane >> 4;
 
-  const int info = cluster_join(p.sync, p.seq, (int*)(smem + CF::NW * CF::W_BYTES));  // (the rings are idle until step 1)
-  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
-  if (info < 0) return;
+  const int joined = cluster_join(p.sync, (int*)(smem + CF::NW * CF::W_BYTES));  // (the rings are idle until step 1)
+  if (joined < 0) return;
+  const int info = joined & 255;                                 // XCD * 32 + slot
+  const unsigned ep0 = (unsigned)(joined >> 8) * kSeqEpochs;     // this launch's number on the sync block
   const int NU = p.NU;
   const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
   const int r0 = p.row0 + cluster * p.Mc;
@@ -634,7 +638,6 @@ __device__ __forceinline__ void db_reduce_add(f32x4 v, float* db_a, float* db_b,
 struct ClBwd {
   int B, T, NU, Mc;
   int row0, nrows;
-  int seq;
   const u16* w_ih_t[2];  // [H,4H] bf16 (l = 1)
   const u16* w_hh_t[2];  // [H,4H]
   const u16* gates;      // (L,T,B,4H) saved activations
@@ -683,9 +686,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
   char* ring = smem + CF::NW * CF::W_BYTES + wave * (kRing * kPanel);  // this wave's staging ring
   const int r = lane & 15, q = lane >> 4;
 
-  const int info = cluster_join(p.sync, p.seq, (int*)(smem + CF::NW * CF::W_BYTES));  // (the rings are idle until step 1)
-  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
-  if (info < 0) return;
+  const int joined = cluster_join(p.sync, (int*)(smem + CF::NW * CF::W_BYTES));  // (the rings are idle until step 1)
+  if (joined < 0) return;
+  const int info = joined & 255;                                 // XCD * 32 + slot
+  const unsigned ep0 = (unsigned)(joined >> 8) * kSeqEpochs;     // this launch's number on the sync block
   const int NU = p.NU;
   const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
   const int r0 = p.row0 + cluster * p.Mc;
@@ -921,9 +925,10 @@ __global__ __launch_bounds__(HW ? kThreads + 64 : kThreads) void lstm_bwd_layer_
   char* ring = smem + CF::W_BYTES + wave * (kRing * kPanel);
   const int r = lane & 15, q = lane >> 4;
 
-  const int info = cluster_join(p.sync, p.seq, (int*)(smem + CF::W_BYTES));
-  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
-  if (info < 0) return;
+  const int joined = cluster_join(p.sync, (int*)(smem + CF::W_BYTES));
+  if (joined < 0) return;
+  const int info = joined & 255;                                 // XCD * 32 + slot
+  const unsigned ep0 = (unsigned)(joined >> 8) * kSeqEpochs;     // this launch's number on the sync block
   const int NU = p.NU;
   const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
   const int r0 = p.row0 + cluster * p.Mc;
@@ -1190,9 +1195,10 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
   const int r = lane & 15, q = lane >> 4;
   const int rt = wave / KSP, kp = wave % KSP;
 
-  const int info = cluster_join(p.sync, p.seq, s_word);
-  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
-  if (info < 0) return;
+  const int joined = cluster_join(p.sync, s_word);
+  if (joined < 0) return;
+  const int info = joined & 255;                                 // XCD * 32 + slot
+  const unsigned ep0 = (unsigned)(joined >> 8) * kSeqEpochs;     // this launch's number on the sync block
   const int NU = p.NU;
   const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
   const int r0 = p.row0 + cluster * p.Mc;
@@ -1395,9 +1401,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
   const int r = lane & 15, q = lane >> 4;
   const int rt = wave / KSP, kp = wave % KSP;
 
-  const int info = cluster_join(p.sync, p.seq, s_word);
-  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
-  if (info < 0) return;
+  const int joined = cluster_join(p.sync, s_word);
+  if (joined < 0) return;
+  const int info = joined & 255;                                 // XCD * 32 + slot
+  const unsigned ep0 = (unsigned)(joined >> 8) * kSeqEpochs;     // this launch's number on the sync block
   const int NU = p.NU;
   const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
   const int r0 = p.row0 + cluster * p.Mc;
@@ -1593,9 +1600,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
   const int r = lane & 15, q = lane >> 4;
   const int kp = wave;
 
-  const int info = cluster_join(p.sync, p.seq, (int*)Part);
-  const unsigned ep0 = (unsigned)p.seq * kSeqEpochs;
-  if (info < 0) return;
+  const int joined = cluster_join(p.sync, (int*)Part);
+  if (joined < 0) return;
+  const int info = joined & 255;                                 // XCD * 32 + slot
+  const unsigned ep0 = (unsigned)(joined >> 8) * kSeqEpochs;     // this launch's number on the sync block
   const int NU = p.NU;
   const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
   const int r0 = p.row0 + cluster * p.Mc;
@@ -1960,7 +1968,6 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     p.sync = (unsigned*)d->lp;
     p.xch = w.xch;
     p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
-    p.seq = (int)(row0 / chunk);
     p.il = getenv("FHVAE_NO_FWD_IL") ? 0 : 1;
     double fl = 0;
     for (int l = 0; l < L; ++l) fl += 2.0 * nrows * 4 * H * ((l > 0 ? d->T * H : 0) + (d->T - 1) * (double)H);
@@ -1974,12 +1981,6 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     if (e) return e;
   }
   return FHVAE_OK;
-}
-
-// the backward re-arms the sync block itself (a plain kernel: memset nodes misbehaved under graph replay), so it does
-// not depend on which form the forward took or on how often the backward runs
-__global__ void cluster_sync_zero_kernel(unsigned* sync) {
-  for (int i = threadIdx.x; i < kSyncWordsUsed; i += blockDim.x) sync[i] = 0u;
 }
 
 template <int H, int L, int RB>
@@ -2080,8 +2081,6 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
   const int NU = H / HU, NC = kGrid / NU;
   const int64_t B = d->B, T = d->T, G = 4 * H;
   const int64_t chunk = (int64_t)NC * (ks ? 32 : 128);
-  hipLaunchKernelGGL(cluster_sync_zero_kernel, dim3(1), dim3(256), 0, st, (unsigned*)d->lp);
-  int seq = 0;
   for (int l = L - 1; l >= 0; --l) {
     for (int64_t row0 = 0; row0 < B; row0 += chunk) {
       const int64_t nrows = B - row0 < chunk ? B - row0 : chunk;
@@ -2093,7 +2092,6 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.NU = NU;
       p.row0 = (int)row0;
       p.nrows = (int)nrows;
-      p.seq = seq++;
       p.w_hh_t[0] = w.w_hh_t[l];
       p.gates = (const u16*)d->gates + (int64_t)l * T * B * G;
       p.cs = d->cs + (int64_t)l * T * B * H;
@@ -2138,7 +2136,6 @@ int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStrea
   if (cluster_form(d) == 1 && (L == 1 || bd->ws_below) && !getenv("FHVAE_NO_LAYERWISE")) return cluster_bwd_layers(bd, w, st);
   const int NU = H / 16, NC = kGrid / NU;
   const int64_t chunk = (int64_t)NC * 128;
-  hipLaunchKernelGGL(cluster_sync_zero_kernel, dim3(1), dim3(256), 0, st, (unsigned*)d->lp);
   for (int64_t row0 = 0; row0 < d->B; row0 += chunk) {
     const int64_t nrows = d->B - row0 < chunk ? d->B - row0 : chunk;
     ClBwd p = {};
@@ -2149,7 +2146,6 @@ int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStrea
     p.NU = NU;
     p.row0 = (int)row0;
     p.nrows = (int)nrows;
-    p.seq = (int)(row0 / chunk);
     for (int l = 0; l < L; ++l) {
       p.w_ih_t[l] = w.w_ih_t[l];
       p.w_hh_t[l] = w.w_hh_t[l];
