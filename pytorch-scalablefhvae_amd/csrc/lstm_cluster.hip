@@ -14,8 +14,9 @@
 //     loads, then reads the operand with sc1 loads.  No agent-scope fence: an L2 write-back / invalidate costs 17+ us per
 //     step (tools/exp/xcd_barrier.hip: 1.1-1.4 us per step for this form, 17-27 us with fences) and is not needed inside
 //     one XCD.  The same-XCD premise is not assumed from blockIdx: a workgroup reads its XCD from the hardware
-//     register and takes a slot by an atomic ticket on that XCD's counter; if an XCD ever received more than 32
-//     workgroups the launch aborts (status word), it never computes from a stale line;
+//     register and takes a slot by an atomic ticket on that XCD's counter (32 tickets per XCD and launch: ticket / 32 is also
+//     the launch's number on the sync block); a workgroup that found its XCD full would hold a ticket of the next launch, wait
+//     for flags nobody raises and end the launch through the bounded spin (status word): it never computes from a stale line;
 //   * every spin is bounded and watches the abort word: a lost workgroup ends the launch, it cannot hang the GPU.
 // Kernels (H in {128, 256}, L <= 2; chosen by rows per cluster, cluster_form):
 //   lstm_fwd_cluster_kernel   forward, both layers as one wavefront, 16 units per member, 64/128 rows per cluster; every
