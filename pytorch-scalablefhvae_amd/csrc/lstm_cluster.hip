@@ -207,7 +207,7 @@ struct ClFwd {
   unsigned* sync;
   unsigned long long* tlog;  // optional phase clock log of cluster 0 / member 0 (tools/prof_cluster.py)
   int il;                    // rows form, L = 2: layer 0's gate math between the MFMAs of the h^1 panels
-  // rows form: the time-constant input xc (B,Ic) bf16 is projected by the kernel itself, once, into layer 0's additive term
+  // the time-constant input xc (B,Ic) bf16 is projected by the kernel itself, once, into layer 0's additive term
   // (W_ih[0][:, I:I+Ic] from w_ih0); `pre` is then NULL and no GEMM runs before the launch
   const u16* xcv;
   int Ic;
@@ -1225,6 +1225,26 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
     bias[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (epi && (kp > 0 || !p.pre)) bias[g] = *(const f32x4*)(p.b_ih[kp] + g * H + uq) + *(const f32x4*)(p.b_hh[kp] + g * H + uq);
   }
+  // the time-constant input's projection (p.xcv): once, by the wave that finishes layer 0, into a constant added to its gates
+  f32x4 pxc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pxc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.xcv && kp == 0) {
+    const int nkc = (p.Ic + 31) / 32, nchc = p.Ic / 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // Ic <= 128
+      if (j >= nkc) break;
+      const int c = j * 4 + q;
+      uint4 xf = uint4{0u, 0u, 0u, 0u};
+      if (c < nchc) xf = *(const uint4*)(p.xcv + rowc * p.Ic + c * 8);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint4 wf = uint4{0u, 0u, 0u, 0u};
+        if (c < nchc) wf = *(const uint4*)(p.w_ih0 + (int64_t)(g * H + u0 + r) * p.K0 + p.I + c * 8);
+        pxc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf), pxc[g], 0, 0, 0);
+      }
+    }
+  }
   f32x4 creg = f32x4{0.f, 0.f, 0.f, 0.f};
   auto pack4 = [](const f32x4& v) -> uint2 {
     return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
@@ -1351,7 +1371,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
       f32x4 gv[4], c;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        gv[g] = (kp == 0 && p.pre) ? padd[g] : bias[g];
+        gv[g] = ((kp == 0 && p.pre) ? padd[g] : bias[g]) + pxc[g];
 #pragma unroll
         for (int k = 0; k < KSP; ++k) gv[g] += *(const f32x4*)(Part + (((rt * KSP + k) * L + kp) * 4 + g) * 1024 + lane * 16);
       }
@@ -1894,18 +1914,10 @@ static void cluster_rows(int64_t nrows, int NC, int* Mc, int* RB) {
   *RB = m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : 128;
 }
 
-// rows form: the forward kernel projects the time-constant input itself (no GEMM, no (B,4H) f32 round trip)
+// the forward kernels project the time-constant input themselves (no GEMM, no (B,4H) f32 round trip)
 bool cluster_xc_in_kernel(const fhvae_lstm_desc* d) {
   if (!(d->Ic > 0 && d->Ic % 8 == 0 && d->Ic <= 128 && d->I % 8 == 0 && (d->I == 0 || cluster_can_fold(d))) || getenv("FHVAE_NO_XC_FOLD"))
     return false;
-  // every launch of the forward (batches beyond one launch run as consecutive row chunks) has to take the rows kernel
-  const int NC = kGrid / ((int)d->H / 16);
-  const int64_t chunk = (int64_t)NC * 128;
-  for (int64_t row0 = 0; row0 < d->B; row0 += chunk) {
-    int Mc, RB;
-    cluster_rows(d->B - row0 < chunk ? d->B - row0 : chunk, NC, &Mc, &RB);
-    if (RB <= 32) return false;
-  }
   return true;
 }
 
@@ -1952,7 +1964,7 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
       p.pre = d->pre;
       p.pre_tstride = d->I > 0 ? d->B * 4 * d->H : 0;
     }
-    if (w.xc_fold) {  // (rows form only, cluster_xc_in_kernel) nothing was left in d->pre: the kernel projects xc itself
+    if (w.xc_fold) {  // (cluster_xc_in_kernel) nothing was left in d->pre: the kernel projects xc itself
       p.xcv = w.xc_fold;
       p.Ic = (int)d->Ic;
       p.w_ih0 = w.w_ih[0];
