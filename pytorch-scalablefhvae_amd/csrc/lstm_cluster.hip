@@ -1599,7 +1599,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
 // ABOVE (a layer below the top): the from-above term dg^{l+1}_t . W_ih[l+1] is computed HERE, from the finished layer above
 // (row-major dg, fetched a step ahead) against W_ih[l+1]^T held in the 128 KB of LDS this kernel no longer needs for its own
 // weights.  It is a K-split partial sum over the same unit tiles as the recurrent product, so it simply starts the accumulators
-// -- and it does not depend on the exchange, so its 64 MFMAs per wave run BEFORE the flag wait, in time that was idle.  The
+// -- and it does not depend on the exchange, so its 64 MFMAs per wave run while the exchange loads are in flight.  The
 // (T*B x 4H x H) GEMM between the two launches of a net and its f32 (T,B,H) round trip are gone.
 template <int H, int RT, bool ABOVE>
 __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
@@ -1718,7 +1718,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int ut = 0; ut < UT; ++ut) acc[rt][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (ABOVE) {  // the from-above term of time t: before the wait (it does not depend on the exchange)
+    // the from-above term of time t (it does not depend on the exchange): issued right behind the exchange loads, so that its
+    // 64 MFMAs per wave run while those loads are in flight
+    auto above_term = [&]() {
+      if constexpr (ABOVE) {
       bf16x8 wu[2][UT];
       auto ufrags = [&](int j, int buf) {
         const int kc = ((kp * KPW + j) << 2) | q;
@@ -1745,6 +1748,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
         }
       }
     }
+    };
     if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
     CL_TLOG(s * 8 + 1);
     if (s > 0) {
@@ -1756,6 +1760,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
         for (int j = 0; j < KPW; ++j) a[rt][j] = load_sc1(dg_rs, base + j * (B * 64));
       }
       __builtin_amdgcn_sched_barrier(0);  // every exchange load is in flight before the first MFMA (the scheduler sinks them otherwise)
+      above_term();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < KPW; ++j)
 #pragma unroll
@@ -1763,6 +1769,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
             acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][ut], __builtin_bit_cast(bf16x8, a[rt][j]), acc[rt][ut], 0, 0, 0);
+    } else {
+      above_term();
     }
     if constexpr (ABOVE) {
       __builtin_amdgcn_sched_barrier(0);
