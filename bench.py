@@ -4,15 +4,24 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(`python -m torch.distributed.run` as a CHILD process, before this process has touched the GPU) and
+passes the one JSON line of rank 0 through.
+
 A "step" = zero_grad -> forward -> loss_function -> backward -> Adam over one synthetic (B,20,80) batch
-already resident in HBM (train_model.py:446-454).  Workload at N=1: BASELINE.json configs[1]
-(fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 4.6k-row mu2 table).  value = segments/s over all ranks.
+already resident in HBM (train_model.py:446-454).  Workload at N=1: BASELINE.json configs[2], the largest
+single-GPU configuration (fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 28k-row mu2 table, batch 2048, bf16);
+configs[1] (4.6k-row table) at batch 2048 and at the reference's default training batch 256 is reported beside
+it as `alt`.  value = segments/s over all ranks.
 Objective: the intended one (decoder attached, log_qy=-CE): the reference's literal `.detach()`
 objective would skip the whole decoder backward, i.e. less work in the timed region.
 """
 import argparse
+import copy
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -22,137 +31,242 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch
-
 CONFIGS = {
     # configs[0]: the reference's own runnable model (FC SimpleFHVAE; "1-layer LSTM" has no referent) on the HIP path
     "c1": dict(H=128, L=2, D=32, S=100, T=20, F=80, B=250, simple=True, desc="simple_fhvae.SimpleFHVAE 128/128 FC, z1=z2=32, 100-seq mu2 table"),
-    # name: (H, layers, D, S, T, F, default per-GPU batch)
-    # SURVEY 8d lists C2 at B=256 (the reference's --training-batch-size default, train_model.py:134-137) and at B=2048
-    # (its --dev-batch-size default): the headline runs the larger one (the cells are launch-latency-bound at 256) and
-    # the B=256 figure is reported next to it in the same JSON line ("alt_batch").
-    "c2": dict(H=256, L=2, D=32, S=4600, T=20, F=80, B=2048, alt_B=256, desc="fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 4.6k-seq mu2 table"),
-    "c3": dict(H=256, L=2, D=32, S=28000, T=20, F=80, B=2048, desc="same model, 28k-seq mu2 table, batch 2048"),
+    # name: (H, layers, D, S, T, F, default per-GPU batch); batch sizes: the reference's --dev-batch-size 2048 and
+    # --training-batch-size 256 defaults (train_model.py:134-137)
+    "c2": dict(H=256, L=2, D=32, S=4600, T=20, F=80, B=2048, desc="fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 4.6k-seq mu2 table"),
+    "c3": dict(H=256, L=2, D=32, S=28000, T=20, F=80, B=2048, desc="fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 28k-seq mu2 table, batch 2048"),
     "c4": dict(H=512, L=2, D=32, S=100000, T=20, F=80, B=2048, desc="2x512 LSTM, 100k-seq mu2 table"),
     "c5": dict(H=256, L=2, D=32, S=1000000, T=40, F=80, B=2048, dtype="f32", desc="1M-seq mu2 table, 40-frame segments, fp32"),
 }
+#: what the default (no --config) run reports beside the headline: (config, per-GPU batch)
+ALT_RUNS = [("c2", 2048), ("c2", 256)]
 
 
-def lstm_flops_fwd(cfg, B):
-    """Algorithmic forward FLOPs of the three LSTM nets: 2*T*sum 4H(I_l+H) per segment."""
-    H, L, D, T, F = cfg["H"], cfg["L"], cfg["D"], cfg["T"], cfg["F"]
-    per_seg = 0
-    for i0 in (F, F + D, 2 * D):
-        for l in range(L):
-            per_seg += 4 * H * ((i0 if l == 0 else H) + H)
-    return 2 * T * per_seg * B
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the ranks as a child process tree.  Nothing in
+    this process has initialised HIP (no torch.cuda call, no library load): the child processes own the GPUs."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
-def synth(cfg, B, device, rank):
-    """SURVEY 8d synthetic inputs (seeds 1234/1235/1236, offset by rank)."""
+# ---------------------------------------------------------------------------------------------
+# synthetic inputs (SURVEY 8d)
+# ---------------------------------------------------------------------------------------------
+def synth_cpu(cfg, B, rank=0, idx_dist="uniform"):
+    """x ~ N(0,1) seed 1234, mu_idx seed 1235 (uniform, or bounded Zipf(1.1) over the S rows: p(r) ~ (r+1)^-1.1, the
+    gather-collision stress), num_segs in [20,200) seed 1236; seeds offset by the rank."""
+    import torch
+
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(B, cfg["T"], cfg["F"], generator=g)
-    idx = torch.randint(0, cfg["S"], (B,), generator=torch.Generator().manual_seed(1235 + rank))
+    gi = torch.Generator().manual_seed(1235 + rank)
+    if idx_dist == "zipf":
+        w = torch.arange(1, cfg["S"] + 1, dtype=torch.float64).pow(-1.1)
+        idx = torch.multinomial(w, B, replacement=True, generator=gi)
+    else:
+        idx = torch.randint(0, cfg["S"], (B,), generator=gi)
     ns = torch.randint(20, 200, (B,), generator=torch.Generator().manual_seed(1236 + rank))
-    return x.to(device), idx.to(device), ns.to(device)
+    return x, idx, ns
 
 
-def cpu_baseline(cfg, B, budget_s=20.0):
-    """The CPU oracle (oracle/ref_cpu.py, kind 'port': the reference's FHVAE is a stub) timed on
-    this box's host cores on a bounded sample of the same workload: full training steps at the same batch."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (BASELINE.md section 3)
+# ---------------------------------------------------------------------------------------------
+def host_cpu_info():
+    """One socket's physical cores, clipped to what this process may actually use (affinity mask, cgroup CPU quota)."""
+    model, cores = "unknown", {}
+    try:
+        phys = core = cpu = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cpu = int(v)
+            elif k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = int(v)
+            elif k == "core id":
+                core = int(v)
+            elif not k and cpu is not None:
+                cores.setdefault((phys or 0, core if core is not None else cpu), []).append(cpu)
+                phys = core = cpu = None
+        if cpu is not None:
+            cores.setdefault((phys or 0, core if core is not None else cpu), []).append(cpu)
+    except OSError:
+        pass
+    allowed = sorted(os.sched_getaffinity(0))
+    sockets = sorted({k[0] for k in cores}) or [0]
+    s0 = sockets[0]
+    # one logical CPU per physical core of the first socket, restricted to the allowed set
+    pin = sorted(min(c for c in cpus if c in allowed) for (s, _), cpus in cores.items()
+                 if s == s0 and any(c in allowed for c in cpus))
+    if not pin:
+        pin = allowed
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    n = len(pin)
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return {"cpu_model": model, "sockets": len(sockets), "socket_physical_cores": sum(1 for k in cores if k[0] == s0) or len(allowed),
+            "allowed_cpus": len(allowed), "cgroup_cpu_quota": quota, "threads": n, "pin": pin[:n]}
+
+
+def cpu_baseline(cfg, dtype, budget_s=45.0, sample_B=256):
+    """the CPU oracle (oracle/ref_cpu.py, kind 'port': the reference's FHVAE is a stub; pure
+    PyTorch, `torch.nn.LSTM` nets, the (B,S,D) materialisation of simple_fhvae.py:119-121) timed on ONE socket of this
+    box: threads = that socket's physical cores (clipped to the cgroup quota / affinity mask), the process pinned to them;
+    fp32; same seeds as the GPU run (1234/1235/1236); 5 warm-up + 10 timed full training steps (fewer if they do not fit the
+    time budget: the record says how many); median.  Sample: the first `sample_B` segments of the seeded batch against the
+    FULL table (the CPU rate is batch-insensitive, SURVEY section 6: 801 vs 1,079 segments/s at 256 vs 2048; at B=2048 the
+    (B,S,D) temporaries of this config are 7.3 GB each).
+    Matched ELBO: the same steps on the same batches and the same draws run on the GPU in f32 (and in the bench's
+    operand dtype) from the same initial weights; ELBO (nats/frame) of the last step's forward is reported for each leg."""
+    import torch
     from oracle import ref_cpu as R
 
+    info = host_cpu_info()
+    old_aff, old_thr = os.sched_getaffinity(0), torch.get_num_threads()
+    try:
+        os.sched_setaffinity(0, info["pin"])
+    except OSError:
+        pass
+    torch.set_num_threads(info["threads"])
     H, L, D, S, T, F = (cfg[k] for k in "HLDSTF")
+    B = min(sample_B, cfg["B"])
+    x, idx, ns = (t[:B] for t in synth_cpu(cfg, cfg["B"]))
     torch.manual_seed(0)
     m = (R.SimpleFHVAERef(T * F, [H] * L, [H] * L, D, D, [H] * L) if cfg.get("simple")
          else R.FHVAERef(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T))
-    table = torch.randn(S, D, requires_grad=True)
+    init_sd = copy.deepcopy(m.state_dict())
+    table0 = torch.randn(S, D, generator=torch.Generator().manual_seed(1))
+    table = table0.clone().requires_grad_(True)
     opt = torch.optim.Adam(list(m.parameters()) + [table], lr=1e-3, betas=(0.95, 0.999))
-    x = torch.randn(B, T, F)
-    idx = torch.randint(0, S, (B,))
-    ns = torch.randint(20, 200, (B,))
-    e2, e1 = torch.randn(B, D), torch.randn(B, D)
-    R.train_step(m, opt, table, x, idx, ns, e2, e1)  # warm-up
-    t0, n = time.time(), 0
-    while True:
-        R.train_step(m, opt, table, x, idx, ns, e2, e1)
-        n += 1
-        if time.time() - t0 > budget_s or n >= 20:
-            break
-    dt = time.time() - t0
-    return {"value": B * n / dt, "unit": "segments/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full training steps (fwd+loss+bwd+Adam) of the torch-CPU oracle %s at B=%d, S=%d, fp32"
-                      % (n, type(m).__name__, B, S)}
+
+    def draws(n):  # per-step reparameterisation draws, the same for every leg
+        g = torch.Generator().manual_seed(1237)
+        return [(torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)) for _ in range(n)]
+
+    eps = draws(15)
+    _, lb = R.train_step(m, opt, table, x, idx, ns, *eps[0])  # first touch (thread pool, allocator): never timed
+    t0 = time.perf_counter()
+    _, lb = R.train_step(m, opt, table, x, idx, ns, *eps[1])
+    t_one = time.perf_counter() - t0
+    # 5 warm-up + 10 timed where the budget allows; otherwise as many as fit (at least 2 + 3)
+    n_warm, n_timed = 5, 10
+    if t_one * 13 > budget_s:
+        fit = int(budget_s / t_one)
+        n_timed = max(3, min(10, fit - 1))
+        n_warm = max(2, min(5, 2 + fit - n_timed))
+    times = []
+    for k in range(2, n_warm + n_timed):
+        t0 = time.perf_counter()
+        _, lb = R.train_step(m, opt, table, x, idx, ns, *eps[k])
+        dt = time.perf_counter() - t0
+        if k >= n_warm:
+            times.append(dt)
+    n_steps = n_warm + n_timed
+    med = statistics.median(times)
+    rec = {"value": B / med, "unit": "segments/s", "cores": info["threads"], "threads": info["threads"], "kind": "port",
+           "median_ms": med * 1e3, "warmup_steps": n_warm, "timed_steps": len(times), "cpu_model": info["cpu_model"],
+           "socket_physical_cores": info["socket_physical_cores"], "sockets": info["sockets"],
+           "cgroup_cpu_quota": info["cgroup_cpu_quota"], "pinned_cpus": len(info["pin"]), "dtype": "f32",
+           "elbo_nats_per_frame": (lb.mean() / T).item(), "elbo_after_steps": n_steps,
+           "sample": "%d+%d full training steps (fwd+loss+bwd+Adam, median of the timed ones) of the torch-CPU oracle %s on the first "
+                     "%d segments of the seeded batch (seeds 1234/1235/1236), full %d-row table with the reference's (B,S,D) "
+                     "materialisation, fp32, %d threads pinned to one socket"
+                     % (n_warm, len(times), type(m).__name__, B, S, info["threads"])}
+    try:
+        os.sched_setaffinity(0, old_aff)
+    except OSError:
+        pass
+    torch.set_num_threads(old_thr)
+
+    # the same n_steps steps on the GPU: f32 (parity mode) and the bench's operand dtype, same initial state, batches, draws
+    if torch.cuda.is_available():
+        from fhvae import FHVAE
+        from hip_optim import FusedAdam
+        from simple_fhvae import SimpleFHVAE
+        from train_model import loss_function
+
+        dev = torch.device("cuda", torch.cuda.current_device())
+        xd, idd, nsd = x.to(dev), idx.to(dev), ns.to(dev)
+        epd = [(a.to(dev), b.to(dev)) for a, b in eps[:n_steps]]
+        for leg in sorted({"f32", dtype}):
+            if cfg.get("simple"):
+                if leg != "f32":
+                    continue
+                gm = SimpleFHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, num_seqs=S, reference_compat=False)
+            else:
+                gm = FHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T, num_seqs=S, reference_compat=False, compute_dtype=leg)
+            gm.load_state_dict(init_sd, strict=False)
+            with torch.no_grad():
+                gm.mu2_table.copy_(table0)
+            gm.to(dev)
+            gopt = FusedAdam(gm.parameters(), lr=1e-3, betas=(0.95, 0.999))
+            for k in range(n_steps):
+                gopt.zero_grad()
+                out = gm(xd, idd, S, nsd, eps=epd[k])
+                loss_function(out[0], out[1], 10.0).backward()
+                gopt.step()
+            e = (out[0].mean() / T).item()
+            rec["gpu_%s_elbo_nats_per_frame" % leg] = e
+            rec["gpu_%s_elbo_rel_diff" % leg] = abs(e - rec["elbo_nats_per_frame"]) / abs(rec["elbo_nats_per_frame"])
+            del gm, gopt, out
+    return rec
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"],
-                    help="MFMA operand type of the LSTM nets (default: the config's -- bf16, configs[4] f32; f32 = exact-f32 parity mode)")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="launch every kernel eagerly instead of replaying the captured hipGraph of the whole step")
-    ap.add_argument("--force-dist", action="store_true", help="use the distributed runner even with one rank (testing)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
-    # stdout carries exactly ONE line (the JSON record): libraries that print banners to fd 1 (RCCL prints its version
-    # block there on communicator creation) are sent to stderr for the whole run
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch.distributed as dist
-
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+# ---------------------------------------------------------------------------------------------
+# one GPU measurement
+# ---------------------------------------------------------------------------------------------
+def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no_graph, want_roofline, idx_dist, dist_graph=False):
+    import torch
 
     import hip_binding as hb
     from fhvae import FHVAE
     from hip_optim import FusedAdam
     from train_model import loss_function
 
-    hb.load_library()
-    cfg = CONFIGS[args.config]
-    args.dtype = args.dtype or cfg.get("dtype", "bf16")
-    B = args.batch or cfg["B"]
+    cfg = CONFIGS[cfg_name]
     H, L, D, S, T, F = (cfg[k] for k in "HLDSTF")
     torch.manual_seed(0)
     if cfg.get("simple"):
         from simple_fhvae import SimpleFHVAE
 
         model = SimpleFHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, num_seqs=S, reference_compat=False).to(device)
-        args.dtype = "f32"
+        dtype = "f32"
     else:
         model = FHVAE(T * F, [H] * L, [H] * L, D, D, [H] * L, seg_len=T, num_seqs=S, reference_compat=False,
-                      compute_dtype=args.dtype).to(device)
+                      compute_dtype=dtype).to(device)
     with torch.no_grad():
         model.mu2_table.copy_(torch.randn(S, D, generator=torch.Generator().manual_seed(1)))
     if use_dist:
+        import torch.distributed as dist
         from dist_shard import DistributedFHVAE
 
         runner = DistributedFHVAE(model, lr=1e-3, betas=(0.95, 0.999))
     else:
         runner = None
         opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.95, 0.999))
-    x, idx, ns = synth(cfg, B, device, rank)
+    x, idx, ns = (t.to(device) for t in synth_cpu(cfg, B, rank, idx_dist))
 
-    def step():
+    def eager_step():
         if runner is not None:
             return runner.train_step(x, idx, ns, alpha=10.0)
         opt.zero_grad()
@@ -164,16 +278,14 @@ def main():
 
     def barrier():
         if use_dist:
-            import torch.distributed as dist
-
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The whole step (zero_grad, forward, loss, backward, collectives excluded, Adam) is ~400 short launches:
-    # capture it once into a hipGraph and replay (single-GPU path; the distributed runner stays eager because
-    # RCCL collectives are enqueued from the host between the phases).
-    use_graph = not args.no_graph and runner is None
-    eager_step = step
+    # The whole step (zero_grad, forward, loss, backward, Adam) is ~110 short launches: capture it once into a hipGraph and
+    # replay.  The distributed runner's step contains RCCL collectives enqueued from the host between the phases: captured
+    # too when asked (--dist-graph; collectives are graph-capturable), eager otherwise.
+    use_graph = (not no_graph) and (runner is None or dist_graph)
+    step = eager_step
     if use_graph:
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)  # capture runs on a side stream by design
         side = torch.cuda.Stream()
@@ -182,7 +294,7 @@ def main():
             for _ in range(3):
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        barrier()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             g_loss, g_lb = eager_step()
@@ -191,17 +303,15 @@ def main():
             graph.replay()
             return g_loss, g_lb
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss, lb = step()
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        import torch.distributed as dist
-
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -209,9 +319,10 @@ def main():
     ok = bool(torch.isfinite(loss).item())
     if hb.lstm_sync_status() != 0:
         raise SystemExit("a persistent LSTM recurrence launch gave up (status %d): results invalid" % hb.lstm_sync_status())
+    res = {"value": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "elbo_nats_per_frame": elbo, "loss_finite": ok,
+           "launch": "hipGraph replay of the whole step" if use_graph else "eager", "dtype": dtype, "batch": B}
 
-    roof = None
-    if not args.no_roofline:  # every rank runs the instrumented steps (they contain collectives); rank 0 reports
+    if want_roofline:  # every rank runs the instrumented steps (they contain collectives); rank 0 reports
         # Instrumented EAGER repeat of the same steps: (1) HIP events (torch's current stream == the launch stream)
         # around every C-ABI call, (2) the library's own per-launch event pairs around every LSTM step-cell
         # launch, each tagged with its algorithmic FLOPs (fhvae_trace_*).  The dominant kernel is the cell kind
@@ -219,7 +330,7 @@ def main():
         hb.OP_TIMER.enable()
         hb.cell_trace(True)
         cells = {}
-        for _ in range(args.steps):
+        for _ in range(steps):
             eager_step()
             for k, (n, t, f) in hb.cell_trace_collect().items():
                 c = cells.get(k, (0, 0.0, 0.0))
@@ -229,100 +340,124 @@ def main():
         per_op = hb.OP_TIMER.summary()
         hb.OP_TIMER.disable()
         form = hb.LAST_LSTM_FORM["form"]  # which schedule the library took for this shape (fhvae_lstm_form)
-        kn = {0: "lstm_%s_step_kernel", 1: "lstm_%s_cluster_kernel", 2: "lstm_%s_ksplit_kernel"}[form]
-        names = {0: kn % "fwd", 1: kn % "bwd"}
-        if form == 1 and not os.environ.get("FHVAE_NO_LAYERWISE"):
-            # rows form: the backward runs one persistent launch per layer (contraction-split variant up to 2048 rows at
-            # H = 256: the library's rule in cluster_bwd_layers)
-            names[1] = "lstm_bwd_layer_ks_kernel" if H == 256 else "lstm_bwd_layer_kernel"
+        names = hb.lstm_kernel_names(form, H)
         if not cells:  # FC model: no LSTM cells to trace
             cells = {0: (1, 1e-9, 0.0)}
         dom = max(cells, key=lambda k: cells[k][1])
         n, t_ms, fl = cells[dom]
         ach = fl / (t_ms * 1e-3) / 1e12
         # dense MFMA peaks (MI355X_MICROARCH.md, matrix cores): bf16 ~2500 TFLOP/s, f32-input 157.3 TFLOP/s
-        peak = 2500.0 if args.dtype == "bf16" else 157.3
+        peak = 2500.0 if dtype == "bf16" else 157.3
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):  # HBM bytes per launch from rocprofv3 --pmc passes of this command (tools/pmc_traffic.py)
             try:
-                traffic = json.load(open(tf)).get("%s_%s_B%d" % (names[dom], args.dtype, B))
+                traffic = json.load(open(tf)).get("%s_%s_B%d" % (names[dom], dtype, B))
             except Exception:
                 traffic = None
-        roof = None if rank != 0 else {"bound": "mfma", "kernel": "%s<%s>" % (names[dom], args.dtype), "achieved": ach, "peak": peak,
-                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                "schedule": hb.LSTM_FORMS[form], "launches_per_step": n / args.steps, "avg_launch_us": t_ms / n * 1e3,
-                "flops_per_launch": fl / n,
-                "cells": {names[k]: {"launches_per_step": v[0] / args.steps, "avg_launch_us": v[1] / v[0] * 1e3,
-                                     "tflops": v[2] / (v[1] * 1e-3) / 1e12} for k, v in cells.items()},
-                "op_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_op.items())}}
+        res["roofline"] = {"bound": "mfma", "kernel": "%s<%s>" % (names[dom], dtype), "achieved": ach, "peak": peak,
+                           "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                           "schedule": hb.LSTM_FORMS[form], "launches_per_step": n / steps, "avg_launch_us": t_ms / n * 1e3,
+                           "flops_per_launch": fl / n,
+                           "cells": {names[k]: {"launches_per_step": v[0] / steps, "avg_launch_us": v[1] / v[0] * 1e3,
+                                                "tflops": v[2] / (v[1] * 1e-3) / 1e12} for k, v in cells.items()},
+                           "op_ms_per_step": {k: v[1] / steps for k, v in sorted(per_op.items())}}
+        if idx_dist == "zipf":
+            cnt = torch.bincount(idx.cpu(), minlength=S)
+            res["idx"] = {"dist": "bounded Zipf(1.1) over the %d rows" % S, "distinct_rows": int((cnt > 0).sum()),
+                          "max_multiplicity": int(cnt.max()),
+                          "k4_gather_bwd_ms": per_op.get("fhvae_mu2_gather_bwd", (0, 0.0))[1] / steps,
+                          "k5_bwd_ms": per_op.get("fhvae_disc_lse_bwd", (0, 0.0))[1] / steps}
+    hb.join_side_stream()
+    return res
 
-    alt = None
-    if world == 1 and not use_dist and cfg.get("alt_B") and not args.batch and not args.no_roofline:
-        # secondary figure at the reference's default training batch (eager launches, same model and optimizer state)
-        Ba = cfg["alt_B"]
-        xa, ia, na = synth(cfg, Ba, device, rank)
-        hb.join_side_stream()
 
-        def step_a():
-            opt.zero_grad()
-            out = model(xa, ia, S, na)
-            l = loss_function(out[0], out[1], 10.0)
-            l.backward()
-            opt.step()
-            return out[0]
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: c3 (the largest single-GPU configuration of BASELINE.json), with the c2 figures as `alt`")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"],
+                    help="MFMA operand type of the LSTM nets (default: the config's -- bf16, configs[4] f32; f32 = exact-f32 parity mode)")
+    ap.add_argument("--idx", default="uniform", choices=["uniform", "zipf"],
+                    help="distribution of mu_idx over the table rows (zipf = bounded Zipf(1.1): the gather-collision stress of SURVEY 8d)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel eagerly instead of replaying the captured hipGraph of the whole step")
+    ap.add_argument("--force-dist", action="store_true", help="use the distributed runner even with one rank (testing)")
+    ap.add_argument("--dist-graph", action="store_true", help="capture the distributed step (collectives included) into a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true")
+    args = ap.parse_args()
 
-        for _ in range(3):
-            step_a()
-        torch.cuda.synchronize()
-        launch_a = "eager"
-        run_a = step_a
-        if use_graph:  # same method as the headline figure: one captured step, replayed
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step_a()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph_a = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_a):
-                g_lba = step_a()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
-            def run_a():
-                graph_a.replay()
-                return g_lba
+    import torch
 
-            launch_a = "hipGraph replay of the whole step"
-            for _ in range(3):
-                run_a()
-            torch.cuda.synchronize()
-        ta = time.perf_counter()
-        for _ in range(args.steps):
-            lba = run_a()
-        torch.cuda.synchronize()
-        ta = time.perf_counter() - ta
-        if hb.lstm_sync_status() != 0:
-            raise SystemExit("a persistent LSTM recurrence launch gave up (alt batch): results invalid")
-        alt = {"batch": Ba, "value": Ba * args.steps / ta, "unit": "segments/s", "ms_per_step": ta / args.steps * 1e3,
-               "launch": launch_a, "elbo_nats_per_frame": (lba.mean() / T).item()}
+    # stdout carries exactly ONE line (the JSON record): libraries that print banners to fd 1 (RCCL prints its version
+    # block there on communicator creation) are sent to stderr for the whole run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        import torch.distributed as dist
+
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import hip_binding as hb
+
+    hb.load_library()
+    default_run = args.config is None
+    cfg_name = args.config or "c3"
+    cfg = CONFIGS[cfg_name]
+    dtype = "f32" if cfg.get("simple") else (args.dtype or cfg.get("dtype", "bf16"))
+    B = args.batch or cfg["B"]
+    T, F = cfg["T"], cfg["F"]
+    main_res = run_gpu(cfg_name, B, dtype, args.steps, args.warmup, device, rank, world, use_dist, args.no_graph,
+                       not args.no_roofline, args.idx, args.dist_graph or (use_dist and world == 1))
+
+    alts = []
+    if default_run and world == 1 and not use_dist and not args.batch and not args.no_alt:
+        for name, b in ALT_RUNS:  # configs[1] at both reference batch sizes, same method as the headline (graph replay)
+            r = run_gpu(name, b, args.dtype or CONFIGS[name].get("dtype", "bf16"), args.steps, 3, device, rank, world, False,
+                        args.no_graph, False, args.idx)
+            alts.append({"workload": "%s: %s; per-GPU batch %d" % (name, CONFIGS[name]["desc"], b), "value": r["value"],
+                         "unit": "segments/s", "ms_per_step": r["ms_per_step"], "launch": r["launch"],
+                         "elbo_nats_per_frame": r["elbo_nats_per_frame"], "dtype": r["dtype"]})
 
     if rank == 0:
         rec = {
-            "metric": "segments/sec + ELBO (nats/frame), (B,20,80) fbank", "value": world * B * args.steps / dt,
+            "metric": "segments/sec + ELBO (nats/frame), (B,20,80) fbank", "value": main_res["value"],
             "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic", "elbo_nats_per_frame": elbo, "loss_finite": ok,
-            "launch": "hipGraph replay of the whole step" if use_graph else "eager",
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": main_res["dtype"], "data": "synthetic", "elbo_nats_per_frame": main_res["elbo_nats_per_frame"],
+            "loss_finite": main_res["loss_finite"], "launch": main_res["launch"],
             "config": {"workload": "%s: %s; per-GPU batch %d, T=%d, F=%d, full train step (fwd+loss+bwd+Adam), "
-                                   "intended objective" % (args.config, cfg["desc"], B, T, F),
+                                   "intended objective, mu_idx %s" % (cfg_name, cfg["desc"], B, T, F, args.idx),
                        "global_batch": world * B, "parallelism": "dp%d+mu2-row-shard" % world if use_dist else "single"},
         }
-        if roof:
-            rec["roofline"] = roof
-        if alt:
-            rec["alt_batch"] = alt
+        for k in ("roofline", "idx"):
+            if k in main_res:
+                rec[k] = main_res[k]
+        if alts:
+            rec["alt"] = alts
         if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(cfg, B)
+            rec["cpu_baseline"] = cpu_baseline(cfg, main_res["dtype"])
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(rec) + "\n").encode())
     if use_dist:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 2
+#define FHVAE_ABI_VERSION 3
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -138,6 +138,9 @@ typedef struct fhvae_lstm_desc {
                     copies of x, xc, the weights and the transposed weights, the backward reuses it.  It also
                     holds the persistent schedules' sync block (first FHVAE_LSTM_SYNC_BYTES) and their exchange
                     buffer (2*L*B*4H bf16): keep it alive and untouched between the forward and its backward */
+  int32_t* sticky_status; /* BF16 mode, optional (may be NULL): int32 device word that is never cleared by the library.  Every
+                    forward ORs the status word its workspace held (the previous forward/backward on it) into it before
+                    re-arming the sync block, so a launch that gave up stays visible however late the host looks. */
 } fhvae_lstm_desc;
 
 int64_t fhvae_lstm_lp_bytes(const fhvae_lstm_desc* d);
@@ -263,9 +266,11 @@ int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, i
 /* The discriminative segment variational lower bound, train_model.py:243-251:
  *   loss = -mean_b(lower_bound[b] + alpha * log_qy) = -(mean(lower_bound) + alpha * log_qy)   (log_qy one f32 on the device)
  * and its backward d_lower_bound[b] = -g/B, d_log_qy = -alpha*g (g = *g_loss, NULL = 1): one launch each instead of the
- * ~10 elementwise/reduction launches of the expression. */
+ * ~10 elementwise/reduction launches of the expression.  nan_flag (optional int32 device word, never cleared here): bit 0 is
+ * set when mean(lower_bound) is NaN -- the loop's divergence test `torch.isnan(lower_bound).any()` (train_model.py:464-466)
+ * without a host synchronisation per batch; the host reads it once per epoch. */
 int fhvae_loss_fwd(const float* lower_bound, const float* log_qy, float alpha, float* loss, int64_t B,
-                   void* stream);
+                   int32_t* nan_flag, void* stream);
 int fhvae_loss_bwd(const float* g_loss, float alpha, float* d_lower_bound, float* d_log_qy, int64_t B,
                    void* stream);
 

@@ -332,14 +332,20 @@ __global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ 
 
 // loss = -(mean(lower_bound) + alpha * log_qy)  (train_model.py:243-251) in one launch, and its backward in one
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ lb, const float* __restrict__ log_qy, float alpha,
-                                                       float* __restrict__ out, int B) {
+                                                       float* __restrict__ out, int B, int* __restrict__ nan_flag) {
   __shared__ float red[4];
   float s = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) s += lb[b];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) *out = -((red[0] + red[1] + red[2] + red[3]) / (float)B + alpha * log_qy[0]);
+  if (threadIdx.x == 0) {
+    const float mean_lb = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+    *out = -(mean_lb + alpha * log_qy[0]);
+    // sticky divergence word (train_model.py:464-466 tests isnan(lower_bound).any() on the host every batch: a NaN in any
+    // element makes the mean NaN, so the same condition is recorded here without a host sync per step)
+    if (nan_flag && mean_lb != mean_lb) atomicOr(nan_flag, 1);
+  }
 }
 __global__ void loss_bwd_kernel(const float* __restrict__ g, float alpha, float* __restrict__ d_lb, float* __restrict__ d_qy,
                                 int64_t B) {
@@ -772,13 +778,14 @@ extern "C" int fhvae_adam_step(float* p, const float* g, float* m, float* v, voi
   return fh_launch_status();
 }
 
-extern "C" int fhvae_loss_fwd(const float* lower_bound, const float* log_qy, float alpha, float* loss, int64_t B, void* stream) {
+extern "C" int fhvae_loss_fwd(const float* lower_bound, const float* log_qy, float alpha, float* loss, int64_t B, int32_t* nan_flag,
+                              void* stream) {
   FH_CHECK_PTR(lower_bound);
   FH_CHECK_PTR(log_qy);
   FH_CHECK_PTR(loss);
   FH_CHECK_POS(B);
   FH_CHECK_I32(B);
-  hipLaunchKernelGGL(loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lower_bound, log_qy, alpha, loss, (int)B);
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lower_bound, log_qy, alpha, loss, (int)B, nan_flag);
   return fh_launch_status();
 }
 

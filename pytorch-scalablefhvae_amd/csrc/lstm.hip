@@ -269,6 +269,7 @@ struct CastItem {
 };
 struct CastBatch {
   unsigned* sync;  // the workspace's sync block (lstm_cluster.h): cleared here, once per forward
+  int* sticky;     // fhvae_lstm_desc.sticky_status: the block's old status word is ORed into it first
   int n;
   CastItem it[4 * FHVAE_MAX_LAYERS + 2];
 };
@@ -276,8 +277,13 @@ struct CastBatch {
 // (the element-wise version wrote the transpose as 2-byte scatters: 13-15 us per net, now ~4)
 __global__ __launch_bounds__(256) void cast_batch_kernel(CastBatch cb) {
   __shared__ u16 tile[32][33];
-  if (blockIdx.x == 0 && blockIdx.y == 0)
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0 && cb.sticky) {  // (thread 0 also clears word 0 below: program order keeps the read first)
+      const unsigned old = cb.sync[kSyncStatus];
+      if (old) atomicOr(cb.sticky, (int)old);
+    }
     for (int i = threadIdx.x; i < kSyncWordsUsed; i += blockDim.x) cb.sync[i] = 0u;
+  }
   const CastItem& c = cb.it[blockIdx.y];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int64_t tr = (c.R + 31) / 32, tc = (c.C + 31) / 32;
@@ -422,6 +428,7 @@ static int cast_operands(const fhvae_lstm_desc* d, hipStream_t st) {
   u16* base = (u16*)d->lp;
   CastBatch cb = {};
   cb.sync = (unsigned*)d->lp;
+  cb.sticky = d->sticky_status;
   auto add = [&](const float* s, u16* dst, u16* dst_t, int64_t R, int64_t C) {
     if (R * C > 0) cb.it[cb.n++] = CastItem{s, dst, dst_t, R, C};
   };

@@ -26,24 +26,30 @@ import torch
 
 
 def scp2dict(path, dtype=str, seqlist=None):
-    """Convert an scp file ("<key> <value>" per line) to an OrderedDict (datasets.py:13-32)."""
-    with open(path) as f:
-        line_list = [line.rstrip().split(None, 1) for line in f]
-    if seqlist is None:
-        return OrderedDict([(k, dtype(v)) for k, v in line_list])
-    return OrderedDict([(k, dtype(v)) for k, v in line_list if k in seqlist])
+    """scp file ("<key> <value>" per line, split at the first blank run) -> OrderedDict in file order, values cast with
+    `dtype`, optionally restricted to the keys in `seqlist` (contract of datasets.py:13-32)."""
+    wanted = None if seqlist is None else set(seqlist)
+    out = OrderedDict()
+    with open(path) as fh:
+        for raw in fh:
+            key, value = raw.rstrip().split(None, 1)
+            if wanted is None or key in wanted:
+                out[key] = dtype(value)
+    return out
 
 
-class Segment(object):
-    """An audio segment: frames [start, end) of sequence `seq` (datasets.py:35-47)."""
+class Segment:
+    """Frames [start, end) of utterance `seq` (the record type of datasets.py:35-47; printed as "seq, start, end")."""
+
+    __slots__ = ("seq", "start", "end")
 
     def __init__(self, seq, start, end):
         self.seq, self.start, self.end = seq, start, end
 
-    def __str__(self):
-        return f"{self.seq}, {self.start}, {self.end}"
+    def __repr__(self):
+        return "%s, %s, %s" % (self.seq, self.start, self.end)
 
-    __repr__ = __str__
+    __str__ = __repr__
 
 
 def make_segs(seqs, lens, seg_len=20, seg_shift=8, rand_seg=False, rng=None):
@@ -65,56 +71,53 @@ def make_segs(seqs, lens, seg_len=20, seg_shift=8, rand_seg=False, rng=None):
 class NumpyDataset(torch.utils.data.Dataset):
     def __init__(self, feat_scp: Path, len_scp: Path, min_len: int = 1, mvn_path: str = None, seg_len: int = 20,
                  seg_shift: int = 8, rand_seg: bool = False, sequence_list=None):
-        feats = scp2dict(feat_scp)
-        lens = scp2dict(len_scp, int, feats.keys())
+        every_feat = scp2dict(feat_scp)
+        every_len = scp2dict(len_scp, int, every_feat.keys())
         self.seg_len, self.seg_shift, self.rand_seg = seg_len, seg_shift, rand_seg
-        if sequence_list is not None:
-            self.seqlist = list(sequence_list)
-        else:
-            self.seqlist = [k for k in feats.keys() if lens[k] >= min_len]
-        self.feats = OrderedDict([(k, feats[k]) for k in self.seqlist])
-        self.lens = OrderedDict([(k, lens[k]) for k in self.seqlist])
-        print(f"{self.__class__.__name__}: {len(self.feats)} out of {len(feats)} kept, min_len = {min_len}")
+        # utterances kept: an explicit list, or all that are at least min_len frames long (datasets.py:80-83)
+        self.seqlist = list(sequence_list) if sequence_list is not None else [k for k, n in every_len.items() if n >= min_len]
+        self.feats = OrderedDict((k, every_feat[k]) for k in self.seqlist)
+        self.lens = OrderedDict((k, every_len[k]) for k in self.seqlist)
+        print("%s: %d out of %d kept, min_len = %s" % (type(self).__name__, len(self.feats), len(every_feat), min_len))
         self.seq_keys = list(self.seqlist)
-        self.seq_feats = [self.feats[k] for k in self.seq_keys]
-        self.seq_lens = [self.lens[k] for k in self.seq_keys]
+        self.seq_feats = list(self.feats.values())
+        self.seq_lens = list(self.lens.values())
         self.segs, self.seq_nsegs = make_segs(self.seq_keys, self.seq_lens, seg_len, seg_shift, rand_seg)
-        self.seq2idx = dict((seq, i) for i, seq in enumerate(self.seq_keys))
+        self.seq2idx = {seq: i for i, seq in enumerate(self.seq_keys)}
         self._mvn_prep(mvn_path)
 
     # -- mean / variance normalisation (datasets.py:100-136, :225-235) -----------------------------
     def _compute_mvn(self):
-        n, x, x2 = 0.0, 0.0, 0.0
-        for seq in self.seqlist:
-            feat = np.load(self.feats[seq])
-            x += np.sum(feat, axis=0, keepdims=True)
-            x2 += np.sum(feat ** 2, axis=0, keepdims=True)
-            n += feat.shape[0]
-        mean = x / n
-        std = np.sqrt(x2 / n - mean ** 2)
-        return {"mean": mean, "std": std}
+        """Per-feature mean and standard deviation over all frames of the kept utterances: first and second moments are
+        summed utterance by utterance in the arrays' own dtype, then std = sqrt(E[x^2] - mean^2) (datasets.py:225-235)."""
+        frames, s1, s2 = 0.0, 0.0, 0.0
+        for path in self.feats.values():
+            a = np.load(path)
+            s1 = s1 + a.sum(axis=0, keepdims=True)
+            s2 = s2 + np.square(a).sum(axis=0, keepdims=True)
+            frames += a.shape[0]
+        mean = s1 / frames
+        return {"mean": mean, "std": np.sqrt(s2 / frames - np.square(mean))}
 
     def _mvn_prep(self, mvn_path):
+        self.mvn_params = None
         if mvn_path is None:
-            self.mvn_params = None
             return
-        if not os.path.exists(mvn_path):
-            self.mvn_params = self._compute_mvn()
-            with open(mvn_path, "w") as f:
-                json.dump({k: np.asarray(v).tolist() for k, v in self.mvn_params.items()}, f)
-        else:
+        if os.path.exists(mvn_path):
             with open(mvn_path) as f:
                 self.mvn_params = {k: np.asarray(v) for k, v in json.load(f).items()}
+        else:
+            self.mvn_params = self._compute_mvn()
+            with open(mvn_path, "w") as f:  # (the reference hands ndarrays to json.dump, datasets.py:111-112: TypeError)
+                json.dump({k: np.asarray(v).tolist() for k, v in self.mvn_params.items()}, f)
 
     def apply_mvn(self, feats):
-        if self.mvn_params is None:
-            return feats
-        return (feats - self.mvn_params["mean"]) / self.mvn_params["std"]
+        p = self.mvn_params
+        return feats if p is None else (feats - p["mean"]) / p["std"]
 
     def undo_mvn(self, feats):
-        if self.mvn_params is None:
-            return feats
-        return feats * self.mvn_params["std"] + self.mvn_params["mean"]
+        p = self.mvn_params
+        return feats if p is None else feats * p["std"] + p["mean"]
 
     def __len__(self):
         return len(self.seqlist)  # number of sequences (datasets.py:138-139): the loop's num_seqs

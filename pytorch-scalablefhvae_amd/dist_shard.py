@@ -34,23 +34,36 @@ class HipBackend:
         hb.load_library()
         self.hb = hb
 
+    # A rank whose shard is empty (more ranks than rows: row0 == row1 == S) still takes part in every collective with the
+    # neutral element of each reduction; the kernels are never launched on zero rows.
     def gather_rows(self, shard, idx_all, row0):
+        if shard.shape[0] == 0:
+            return torch.zeros(idx_all.shape[0], shard.shape[1], device=shard.device, dtype=torch.float32)
         return self.hb.raw_gather_rows(shard, idx_all, row0)
 
     def scatter_rows_(self, dshard, drows, idx_all, row0, scale):
+        if dshard.shape[0] == 0:
+            return
         self.hb.raw_scatter_rows_(dshard, drows, idx_all, row0, scale)
 
     def disc_partials(self, q_all, shard, idx_all, row0):
+        if shard.shape[0] == 0:
+            n = q_all.shape[0]
+            z = torch.zeros(n, device=q_all.device, dtype=torch.float32)
+            return torch.full_like(z, -float("inf")), z, z.clone()
         rmax, rsum, tgt, _ = self.hb.raw_disc_fwd(q_all, shard, idx_all, row0=row0, want_ce=False)
         return rmax, rsum, tgt
 
     def disc_rescale(self, rmax, rsum, m):
+        # an empty shard's (-inf, 0) partial rescales to 0 * exp(-inf) = 0 in the kernel: no special case
         return self.hb.raw_disc_rescale(rmax, rsum, m)
 
     def ce_mean(self, m, s, tgt):
         return self.hb.raw_disc_ce_mean(m, s, tgt)
 
     def disc_bwd(self, q_all, shard, idx_all, row0, m, s, g, g_mul, need_dq, need_dt):
+        if shard.shape[0] == 0:
+            return (torch.zeros_like(q_all) if need_dq else None), (torch.zeros_like(shard) if need_dt else None)
         return self.hb.raw_disc_bwd(q_all, shard, idx_all, m, s, g, g_mul, row0=row0, need_dq=need_dq, need_dt=need_dt)
 
 
@@ -280,6 +293,72 @@ class DistributedFHVAE:
             elif e > b:
                 self.sh.all_reduce_(flat[b:e])
         self._pending.clear()
+
+    # -- checkpointing: the full table (and its Adam moments) exists only as row shards ----------------------------------
+    def _gather_rows(self, local: torch.Tensor) -> torch.Tensor:
+        """Concatenate per-rank row blocks (rank order = row order) on every rank; shards are padded to `per` rows for the
+        equal-size collective and the padding is cut off again."""
+        sh = self.sh
+        pad = local.new_zeros((sh.per,) + tuple(local.shape[1:]))
+        pad[: local.shape[0]] = local
+        return sh.all_gather(pad)[: sh.S]
+
+    def gather_table(self) -> torch.Tensor:
+        """The whole (S, D) mu2 table on every rank (north_star's all-gather of mu2 shards: checkpoint / evaluation only,
+        never on the training step)."""
+        return self._gather_rows(self.shard.data)
+
+    def state_dict(self) -> dict:
+        """Single-GPU-compatible state: the model's state_dict with the gathered `mu2_table`, and one Adam state in
+        torch.optim.Adam's layout over (net parameters in model.named_parameters() order ..., mu2_table) -- what
+        FusedAdam(model.parameters()).state_dict() holds on one GPU.  Collective: call on every rank."""
+        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        sd["mu2_table"] = self.gather_table()
+        nets = self.opt_nets.state_dict()
+        tab = self.opt_table.state_dict()
+        names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+        order = {id(p): i for i, p in enumerate(self.opt_nets._params)}
+        state = {}
+        for j, n in enumerate(names):
+            state[j] = nets["state"][order[id(dict(self.model.named_parameters())[n])]]
+        t = tab["state"][0]
+        state[len(names)] = {"step": t["step"], "exp_avg": self._gather_rows(t["exp_avg"]),
+                             "exp_avg_sq": self._gather_rows(t["exp_avg_sq"])}
+        groups = [dict(nets["param_groups"][0], params=list(range(len(names) + 1)))]
+        return {"state_dict": sd, "optimizer": {"state": state, "param_groups": groups}, "param_names": names + ["mu2_table"]}
+
+    def load_state_dict(self, full: dict):
+        """Inverse of state_dict(): every rank passes the same full state and keeps its own rows."""
+        sh = self.sh
+        sd = dict(full["state_dict"])
+        table = sd.pop("mu2_table")
+        self.model.load_state_dict(sd, strict=False)
+        with torch.no_grad():
+            self.shard.data.copy_(table[sh.row0:sh.row1].to(self.shard.device))
+        opt = full.get("optimizer")
+        if opt is not None:
+            names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+            by_name = dict(self.model.named_parameters())
+            pos = {id(by_name[n]): j for j, n in enumerate(names)}
+            st = opt["state"]
+            nets_state = {i: st[pos[id(p)]] for i, p in enumerate(self.opt_nets._params) if pos[id(p)] in st}
+            g = dict(opt["param_groups"][0])
+            self.opt_nets.load_state_dict({"state": nets_state, "param_groups": [dict(g, params=list(range(len(self.opt_nets._params))))]})
+            t = st.get(len(names))
+            if t is not None:
+                rows = {"step": t["step"], "exp_avg": t["exp_avg"][sh.row0:sh.row1], "exp_avg_sq": t["exp_avg_sq"][sh.row0:sh.row1]}
+                self.opt_table.load_state_dict({"state": {0: rows}, "param_groups": [dict(g, params=[0])]})
+
+    def check_status(self) -> int:
+        """One host sync (call once per epoch / before a checkpoint, not per step): 0 = healthy; 2 = a NaN lower bound was seen
+        (train_model.py:464-466); 3 = a persistent LSTM recurrence launch gave up (e.g. a collective kernel held CUs while it
+        ran): results since are invalid.  The worst code over all ranks is returned on every rank."""
+        import hip_binding as hb
+
+        code = 2 if hb.diverged(self.shard.device) else (3 if hb.lstm_sync_status() != 0 else 0)
+        t = torch.tensor([code], device=self.shard.device, dtype=torch.int32)
+        self.sh.all_reduce_(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
 
     def train_step(self, x, idx, nsegs, alpha=10.0):
         from train_model import loss_function

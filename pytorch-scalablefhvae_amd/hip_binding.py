@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
 
 F32, BF16 = 0, 1
 MAX_LAYERS = 4
+ABI_VERSION = 3  # FHVAE_ABI_VERSION of include/fhvae_hip.h
 #: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
 INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
@@ -34,6 +35,7 @@ class LstmDesc(C.Structure):
         ("w_ih", _vp * MAX_LAYERS), ("w_hh", _vp * MAX_LAYERS),
         ("b_ih", _vp * MAX_LAYERS), ("b_hh", _vp * MAX_LAYERS),
         ("hs", _vp), ("cs", _vp), ("gates", _vp), ("hn", _vp), ("hs_top_f32", _vp), ("pre", _vp), ("lp", _vp),
+        ("sticky_status", _vp),
     ]
 
 
@@ -81,7 +83,7 @@ SIGNATURES = {
     "fhvae_gauss_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fhvae_gauss_head_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_gauss_head_bwd_lp": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
-    "fhvae_loss_fwd": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _vp]),
+    "fhvae_loss_fwd": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _vp, _vp]),
     "fhvae_loss_bwd": (C.c_int, [_vp, _f32, _vp, _vp, _i64, _vp]),
     "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_form": (C.c_int, [C.POINTER(LstmDesc)]),
@@ -124,7 +126,7 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fhvae_abi_version() != 2:
+    if lib.fhvae_abi_version() != ABI_VERSION:
         raise RuntimeError("libfhvae_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -482,6 +484,31 @@ def _fill_lstm_desc(d, dtype, dims, x_tm, xc, params, x_lp=None):
     d.x_lp = _p(x_lp) if dtype == BF16 else None
     for l in range(L):
         d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_p(params[4 * l + k]) for k in range(4))
+    d.sticky_status = _p(_device_words(params[0].device)) if dtype == BF16 else None
+
+
+# Two sticky int32 device words per GPU, never cleared by the library: [0] = OR of the status words of every persistent
+# recurrence launch that gave up (fhvae_lstm_desc.sticky_status), [1] = the divergence flag of fhvae_loss_fwd (nan_flag).
+# The training loops read them once per epoch / before a checkpoint instead of synchronising every batch.
+_DEVICE_WORDS: dict = {}
+
+
+def _device_words(device) -> torch.Tensor:
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    w = _DEVICE_WORDS.get(key)
+    if w is None:
+        w = _DEVICE_WORDS[key] = torch.zeros(4, device=torch.device("cuda", key), dtype=torch.int32)
+    return w
+
+
+def diverged(device=None) -> bool:
+    """True once any fhvae_loss_fwd on this device has seen a NaN lower bound (train_model.py:464-466's test; one sync)."""
+    w = _device_words(device if device is not None else torch.cuda.current_device())
+    return bool(w[1].item() != 0)
+
+
+def reset_device_words(device=None):
+    _device_words(device if device is not None else torch.cuda.current_device()).zero_()
 
 
 # the most recent bf16 workspaces (fhvae_lstm_desc.lp): word 0 of each is the status of the persistent recurrence
@@ -494,10 +521,24 @@ LSTM_FORMS = {0: "one launch per wavefront step", 1: "persistent cluster kernel 
 LAST_LSTM_FORM = {"form": 0}
 
 
+def lstm_kernel_names(form: int, H: int) -> dict:
+    """{0: forward, 1: backward} kernel names of the recurrence schedule `form` (fhvae_lstm_form) as rocprofv3 lists them."""
+    kn = {0: "lstm_%s_step_kernel", 1: "lstm_%s_cluster_kernel", 2: "lstm_%s_ksplit_kernel"}[form]
+    names = {0: kn % "fwd", 1: kn % "bwd"}
+    if form == 1 and not os.environ.get("FHVAE_NO_LAYERWISE"):
+        # rows form: the backward runs one persistent launch per layer (contraction-split variant at H = 256)
+        names[1] = "lstm_bwd_layer_ks_kernel" if H == 256 else "lstm_bwd_layer_kernel"
+    return names
+
+
 def lstm_sync_status() -> int:
-    """OR of the status words of the recent bf16 LSTM workspaces (synchronises).  Non-zero: a persistent recurrence
-    launch gave up (bounded spin expired / unexpected workgroup placement) and its outputs are invalid."""
+    """OR of the sticky per-device status words (every earlier forward folds its workspace's previous status into them) and
+    of the status words of the most recent bf16 LSTM workspaces (synchronises).  Non-zero: a persistent recurrence launch
+    gave up at some point since the process started (bounded spin expired / unexpected workgroup placement): every result
+    computed since is suspect."""
     st = 0
+    for w in _DEVICE_WORDS.values():
+        st |= int(w[0].item())
     for lp in LSTM_WORKSPACES:
         st |= int(lp[:4].view(torch.int32).item())
     return st
@@ -754,7 +795,8 @@ class _FusedLoss(torch.autograd.Function):
         lb, qy = _f32c(lower_bound), _f32c(log_qy)
         out = torch.empty((), device=lb.device, dtype=torch.float32)
         with _Timed("fhvae_loss_fwd"):
-            _check(lib.fhvae_loss_fwd(_p(lb), _p(qy), float(alpha), _p(out), lb.numel(), _stream()), "fhvae_loss_fwd")
+            _check(lib.fhvae_loss_fwd(_p(lb), _p(qy), float(alpha), _p(out), lb.numel(), _device_words(lb.device)[1:].data_ptr(),
+                                      _stream()), "fhvae_loss_fwd")
         ctx.alpha, ctx.B = float(alpha), lb.numel()
         return out
 
@@ -847,6 +889,8 @@ def adam_step_(p, g, m, v, step_dev, lr, beta1, beta2, eps, grad_scale=1.0, p_lp
     lib = load_library()
     _need_gpu(p, g, m, v, step_dev)
     n = p.numel()
+    if n == 0:  # an empty table shard (more ranks than rows)
+        return
     with _Timed("fhvae_adam_step"):
         _check(lib.fhvae_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, lr, beta1, beta2, eps, grad_scale, _p(step_dev),
                                    _stream()), "fhvae_adam_step")

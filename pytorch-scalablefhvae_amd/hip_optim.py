@@ -49,6 +49,48 @@ class FusedAdam(torch.optim.Optimizer):
         self.v = torch.zeros_like(self.p_arena.flat)
         self.step_dev = torch.zeros((), device=params[0].device, dtype=torch.int32)
 
+    # -- checkpoint contract (utils.py:87,131; train_model.py:415): torch.optim.Adam's state-dict layout, so the moments and the
+    # step count survive a save / resume and a state saved by torch.optim.Adam over the same parameters loads here -----------
+    def state_dict(self):
+        sd = super().state_dict()  # param_groups (+ parameter indices); Optimizer.state itself is empty: the arenas hold it
+        step = float(self.step_dev.item())
+        state = {}
+        for i, (off, p) in enumerate(zip(self.p_arena.offsets, self._params)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(step), "exp_avg": self.m[off:off + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.v[off:off + n].view(p.shape).clone()}
+        sd["state"] = state
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self._params):
+            raise ValueError("FusedAdam.load_state_dict: expected one parameter group of %d parameters" % len(self._params))
+        g = self.param_groups[0]
+        for k in ("lr", "betas", "eps"):
+            if k in groups[0]:
+                g[k] = groups[0][k] if k != "betas" else tuple(groups[0][k])
+        state = state_dict.get("state", {})
+        steps = set()
+        self.m.zero_()
+        self.v.zero_()
+        for j, key in enumerate(groups[0]["params"]):
+            st = state.get(key, state.get(str(key)))
+            if st is None:
+                continue
+            off, p = self.p_arena.offsets[j], self._params[j]
+            n = p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("FusedAdam.load_state_dict: moment shape %s does not match parameter %s"
+                                 % (tuple(st["exp_avg"].shape), tuple(p.shape)))
+            self.m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(self.m.device, torch.float32))
+            self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device, torch.float32))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdam keeps ONE step count for all parameters; the state holds %s" % sorted(steps))
+        self.step_dev.fill_(steps.pop() if steps else 0)
+
     def zero_grad(self, set_to_none: bool = False):
         # keep the arena views attached (set_to_none would detach them); one memset for everything
         hb.join_side_stream()

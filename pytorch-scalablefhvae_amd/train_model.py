@@ -86,8 +86,17 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--hip-graph", action="store_true",
                    help="capture one training step (zero_grad, forward, loss, backward, Adam) into a hipGraph and replay it for "
                         "every full-size batch (static input buffers; a smaller last batch runs eagerly)")
-    p.add_argument("--paper-objective", action="store_true",
-                   help="train the intended objective (decoder attached, log_qy=-CE) instead of the reference's literal one")
+    p.add_argument("--reference-objective", action="store_true",
+                   help="train the reference's LITERAL objective: decoder outputs and mu2 detached inside the bound "
+                        "(simple_fhvae.py:107,114) and log_qy = +CE (:122).  With a persistent learnable mu2 table that "
+                        "objective pushes CE up without bound and gives the decoder no gradient; the default is the intended "
+                        "objective (decoder trained, log_qy = -CE), which is also what bench.py and the README figures use")
+    p.add_argument("--paper-objective", action="store_true", help="(accepted for compatibility: this is the default now)")
+    p.add_argument("--continue-from", default=None,                 # train_model.py:192-197
+                   help="checkpoint file (utils.save_checkpoint layout) to resume from: model, mu2 table, Adam moments and step")
+    p.add_argument("--check-interval", type=int, default=100,
+                   help="batches between reads of the device-side divergence / recurrence-status words (each read is a host "
+                        "sync; they are always read at the end of an epoch and before a checkpoint)")
     return p
 
 
@@ -124,7 +133,10 @@ def main(argv=None) -> int:
     else:
         S = args.num_seqs
     input_size = T * F  # np.prod(example_data.shape), train_model.py:396-398
-    kw = dict(num_seqs=S, reference_compat=not args.paper_objective)
+    kw = dict(num_seqs=S, reference_compat=bool(args.reference_objective))
+    if args.reference_objective:
+        print("WARNING: --reference-objective trains the reference's literal loss (+CE, detached decoder); "
+              "throughput/ELBO figures of this build use the default objective", file=sys.stderr)
     if args.model_type == "fhvae":
         model = FHVAE(input_size, args.z1_hus, args.z2_hus, args.z1_dim, args.z2_dim, args.x_hus, seg_len=T,
                       compute_dtype=args.compute_dtype, **kw)
@@ -134,6 +146,23 @@ def main(argv=None) -> int:
     from hip_optim import FusedAdam
 
     optimizer = FusedAdam(model.parameters(), lr=args.learning_rate, betas=(args.beta_one, args.beta_two))
+    import hip_binding as hb
+
+    start_epoch = 0
+    best_epoch, best_val_lb = 0, -np.inf
+    if args.continue_from:
+        # resume (train_model.py:303-322 -> utils.load_checkpoint_file): weights + table into the live model, Adam moments and
+        # step count into the arenas; the reference's own branch never rebuilds the optimizer (dead path)
+        from utils import load_checkpoint_file
+
+        ck_model, _values, optim_state, start_epoch, ck_best, _ = load_checkpoint_file(args.continue_from, False, input_size=input_size)
+        model.load_state_dict(ck_model.state_dict(), strict=True)
+        if optim_state is not None:
+            optimizer.load_state_dict(optim_state)
+        if ck_best is not None:
+            best_val_lb = float(ck_best)
+        best_epoch = start_epoch - 1
+        print(f"resumed from {args.continue_from}: starting at epoch {start_epoch}")
 
     if real:
         def train_batches():
@@ -198,6 +227,9 @@ def main(argv=None) -> int:
             return train_step(idxs, features, nsegs)
         if graph is None:
             st_i, st_x, st_n = idxs.clone(), features.clone(), nsegs.clone()
+            # the warm-up steps and the capture must not train: parameters, Adam moments and the step count are put back
+            # afterwards, so this batch gets exactly one update (the first replay) like every other batch
+            keep = [t.clone() for t in (optimizer.p_arena.flat, optimizer.m, optimizer.v, optimizer.step_dev)]
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -209,7 +241,11 @@ def main(argv=None) -> int:
             with torch.cuda.graph(g):
                 outs = train_step(st_i, st_x, st_n)
             graph = (g, (st_i, st_x, st_n), outs)
-            return outs  # (the two warm-up steps and the capture trained on this batch)
+            for t, k in zip((optimizer.p_arena.flat, optimizer.m, optimizer.v, optimizer.step_dev), keep):
+                t.copy_(k)
+            # capture only RECORDS the kernels: `outs` is uninitialised graph-pool memory until the first replay
+            g.replay()
+            return outs
         g, (st_i, st_x, st_n), outs = graph
         st_i.copy_(idxs)
         st_x.copy_(features)
@@ -217,8 +253,21 @@ def main(argv=None) -> int:
         g.replay()
         return outs
 
-    best_epoch, best_val_lb = 0, -np.inf
-    for epoch in range(args.epochs):
+    def healthy() -> Optional[int]:
+        """One host sync: the sticky device words.  Divergence = NaN lower bound in ANY batch since the start
+        (fhvae_loss_fwd's nan_flag; the reference tests every batch on the host, train_model.py:464-466).  Recurrence status
+        = a persistent bf16 LSTM launch gave up (all 256 CUs were not co-resident): everything computed since is invalid."""
+        if hb.diverged(device):
+            print("Training diverged")
+            return 2  # sys.exit(2), train_model.py:464-466
+        st = hb.lstm_sync_status()
+        if st != 0:
+            print("a persistent LSTM recurrence launch gave up (status %d): results since are invalid; rerun with "
+                  "FHVAE_NO_CLUSTER=1 if the GPU is shared" % st, file=sys.stderr)
+            return 3
+        return None
+
+    for epoch in range(start_epoch, args.epochs):
         model.train()
         t0 = time.time()
         train_loss = torch.zeros((), device=device)
@@ -227,9 +276,13 @@ def main(argv=None) -> int:
             loss, lower_bound = graph_step(idxs, features, nsegs)
             train_loss += loss
             nb += 1
-            if torch.isnan(lower_bound).any():
-                print("Training diverged")
-                return 2  # sys.exit(2), train_model.py:464-466
+            if args.check_interval > 0 and nb % args.check_interval == 0:
+                rc = healthy()
+                if rc is not None:
+                    return rc
+        rc = healthy()  # end of epoch, and before anything is checkpointed
+        if rc is not None:
+            return rc
         dt = time.time() - t0
         print(f"====> Train set average loss: {train_loss.item() / nb:.4f}  ({n_train / dt:.0f} segments/s)")
         model.eval()

@@ -1,5 +1,5 @@
 """utils.py -- the parts of the reference's utils.py that touch the hot path's state (utils.py:14-152):
-checkpoint layout, run naming, args pickle, and the closed-form mu2 estimate.  AudioUtils (librosa wrappers,
+checkpoint layout, args pickle, and the closed-form mu2 estimate (run naming, utils.py:20-42, is CLI plumbing: not built).  AudioUtils (librosa wrappers,
 utils.py:155-300) is offline feature extraction and out of scope.
 """
 from __future__ import annotations
@@ -18,23 +18,6 @@ from simple_fhvae import SimpleFHVAE
 def check_best(val_lower_bound, best_val_lb) -> bool:
     """utils.py:14-17."""
     return bool(torch.mean(val_lower_bound) > best_val_lb)
-
-
-def create_output_dir_name(dataset: str, data_format: str, feat_type: str) -> Path:
-    """utils.py:32-42."""
-    dataset += "_np" if data_format.lower() == "numpy" else "_kd"
-    feat_type = "fbank" if data_format == "kaldi" else feat_type
-    return Path(dataset + f"_{feat_type}")
-
-
-def create_training_strings(args):
-    """utils.py:20-29."""
-    base_string = create_output_dir_name(args.dataset, args.data_format, args.feat_type)
-    if args.legacy:
-        exp_string = f"{args.model_type}_e{args.epochs}_s{args.steps_per_epoch}_p{args.patience}_a{args.alpha_dis}_legacy"
-    else:
-        exp_string = f"{args.model_type}_e{args.epochs}_p{args.patience}_a{args.alpha_dis}"
-    return base_string, exp_string, f"{base_string}_{exp_string}"
 
 
 def estimate_mu2_dict(model, loader, num_seqs):

@@ -16,6 +16,12 @@ Fixtures:
         draws, the 6 forward outputs, loss_function(alpha=10) and all gradients (+ table.grad).
   simple_refshape_f32.npz : T=20,F=80, hus 128/128, D=16, B=64, S=100; weights/x from the closed-form
         ``oracle.ref_cpu.det_tensor`` (regenerable), draws + 6 outputs + loss stored.
+  ref_checkpoint_simple_tiny.tar : a checkpoint in the reference's EXACT dict layout (utils.py:131-146: 5-value
+        `model_params`, plain `state_dict()`, `optimizer.state_dict()` of torch.optim.Adam(lr, betas=(0.95, 0.999)),
+        train_model.py:409-411) written from the imported reference model after one reference training step on the
+        tiny fixture's inputs; plus the 6 forward outputs of the UPDATED model on the same inputs/draws.  (The reference's
+        own `utils.save_checkpoint` cannot be imported -- utils.py:1,4 need librosa/nptyping -- so the dict literal
+        follows utils.py:131-146 key by key; the values all come from reference objects.)
   disc_{8x12,256x4600}.npz : the discriminative block alone (simple_fhvae.py:119-122): q=z2_mu, table,
         idx -> log_qy, d log_qy/dq, d log_qy/dtable, taken from inside a reference forward.
 """
@@ -120,6 +126,41 @@ def tiny(dtype, name):
     print(name, "loss", float(loss), "no-grad params:", [n for n, p in model.named_parameters() if p.grad is None])
 
 
+def ref_checkpoint():
+    T, F, D, B, S = 4, 8, 16, 8, 12
+    g = dict(np.load(os.path.join(HERE, "simple_tiny_f32.npz")))
+    torch.manual_seed(7)
+    model = ref.SimpleFHVAE(T * F, [16, 16], [16, 16], D, D, [16, 16])
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd_")})
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.95, 0.999))  # train_model.py:409-411
+    x, idx, nsegs = torch.from_numpy(g["x"]), torch.from_numpy(g["idx"]), torch.from_numpy(g["nsegs"])
+    optimizer.zero_grad()
+    out, rec = run(model, x, idx, S, nsegs, seed=11)        # same seed as tiny(): same table and draws
+    loss = ref_loss_function(out[0], out[1], 10.0)
+    loss.backward()
+    optimizer.step()                                        # train_model.py:446-454
+    with torch.no_grad():
+        out2, rec2 = run(model, x, idx, S, nsegs, seed=11)  # the updated model on the same inputs/draws
+    checkpoint = {                                          # utils.py:131-146, key by key
+        "best_val_lb": float(torch.mean(out2[0])),
+        "best_epoch": 3,
+        "epoch": 3,
+        "model_type": model.model,
+        "model_params": (model.z1_hus, model.z2_hus, model.z1_dim, model.z2_dim, model.x_hus),
+        "optimizer": optimizer.state_dict(),
+        "state_dict": model.state_dict(),
+        "summary_vals": None,
+        "values": {"val_lower_bound": float(torch.mean(out2[0]))},
+    }
+    torch.save(checkpoint, os.path.join(HERE, "ref_checkpoint_simple_tiny.tar"))
+    d = {"table": np_(rec2.table), "eps_z2": np_(rec2.draws[0]), "eps_z1": np_(rec2.draws[1])}
+    for k, name_o in enumerate(["lower_bound", "log_qy", "log_px_z", "neg_kld_z1", "neg_kld_z2", "log_pmu2"]):
+        d["out_" + name_o] = np_(out2[k])
+    np.savez_compressed(os.path.join(HERE, "ref_checkpoint_simple_tiny_outputs.npz"), **d)
+    print("ref_checkpoint_simple_tiny.tar: loss before the step", float(loss), "params with Adam state:",
+          len(checkpoint["optimizer"]["state"]))
+
+
 def refshape():
     T, F, D, B, S = 20, 80, 16, 64, 100
     model = ref.SimpleFHVAE(T * F)  # defaults 128/128, 16/16  (simple_fhvae.py:9-17)
@@ -156,8 +197,12 @@ def disc(B, S, name):
 
 
 if __name__ == "__main__":
+    if "--checkpoint-only" in sys.argv:
+        ref_checkpoint()
+        sys.exit(0)
     tiny(torch.float32, "simple_tiny_f32.npz")
     tiny(torch.float64, "simple_tiny_f64.npz")
     refshape()
     disc(8, 12, "disc_8x12.npz")
     disc(256, 4600, "disc_256x4600.npz")
+    ref_checkpoint()

@@ -1,0 +1,250 @@
+"""Parity of the shapes BASELINE.json's configs name that the other GPU tests do not reach (VERDICT r01 `configs_untested`):
+
+  configs[0]  SimpleFHVAE at z1 = z2 = 32 end to end (the reference itself only runs at 16/16, SURVEY 0.3: the restatement,
+              which is bit-equal to the reference at 16/16, is the oracle at 32/32)
+  configs[1]/[2]  the kernels the bench's roofline names, at the bench's batch (B = 2048, H = 256, bf16): forward AND backward
+              (all eight weight gradients + d_xc) against torch.nn.LSTM, not only against the step kernels
+  configs[3]  2x512 LSTM: f32 (1e-4) and bf16 against torch.nn.LSTM; the bf16 FHVAE at H = 512 end to end
+  configs[4]  40-frame segments in f32 end to end against FHVAERef
+plus the element-wise form of north_star's "1e-4 relative fp32" on the six forward outputs, and the discriminative loss
+in the regime training converges to (queries next to their own table row, large table norms), where the MFMA form's
+expansion 2c q.t - c|q|^2 - c|t|^2 cancels.
+Tolerances are written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R
+from test_ops_gpu import close, dev, hb  # noqa: F401
+
+OUT = ["lower_bound", "log_qy", "log_px_z", "neg_kld_z1", "neg_kld_z2", "log_pmu2"]
+
+
+def close_elementwise(got, want, rtol=1e-4, atol=1e-5, what=""):
+    """|got - want| <= atol + rtol * |want| for EVERY element (north_star: "within 1e-4 relative fp32"); atol 1e-5 only
+    covers elements that are themselves ~0 (a KL term of a nearly-prior posterior)."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    torch.testing.assert_close(got, want, rtol=rtol, atol=atol, msg=lambda m: "%s (element-wise): %s" % (what, m))
+
+
+def _lstm_case(hb, B, T, I, Ic, H, L, dt, seed):
+    torch.manual_seed(seed)
+    dtype = hb.BF16 if dt == "bf16" else hb.F32
+    lstm = torch.nn.LSTM(I + Ic, H, L, batch_first=True)
+    x = torch.randn(B, T, I) if I else None
+    xc = torch.randn(B, Ic, requires_grad=True) if Ic else None
+    parts = ([x] if I else []) + ([xc[:, None, :].expand(B, T, Ic)] if Ic else [])
+    out, (hn, _) = lstm(torch.cat(parts, -1))
+    hn_cat = torch.cat([hn[l] for l in range(L)], -1)
+    g_out, g_hn = torch.randn(B, T, H), torch.randn(B, L * H)
+    ((out * g_out).sum() + (hn_cat * g_hn).sum()).backward()
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    params = [dev(getattr(lstm, n).detach()).requires_grad_(True) for n in names]
+    x_tm = dev(x.transpose(0, 1).contiguous()) if I else None
+    xcd = dev(xc.detach()).requires_grad_(True) if Ic else None
+    hs_top, hnd = hb.lstm_seq(x_tm, xcd, T, params, dtype)
+    ((hs_top * dev(g_out.transpose(0, 1).contiguous())).sum() + (hnd * dev(g_hn)).sum()).backward()
+    torch.cuda.synchronize()
+    assert hb.lstm_sync_status() == 0, "a persistent recurrence launch gave up"
+    return lstm, names, params, (out, hn_cat, xc), (hs_top, hnd, xcd)
+
+
+@pytest.mark.parametrize("B,T,I,Ic,H,L,dt", [(64, 20, 80, 0, 512, 2, "f32"), (64, 20, 80, 32, 512, 2, "f32"),
+                                             (64, 20, 80, 32, 512, 2, "bf16"), (256, 20, 0, 64, 512, 2, "bf16"),
+                                             (32, 40, 80, 32, 256, 2, "f32")])
+def test_lstm_h512_and_t40_vs_torch_lstm(hb, B, T, I, Ic, H, L, dt):
+    """configs[3] (H = 512) and configs[4] (T = 40, f32).  f32: 1e-4 of the tensor's max (exact-f32 MFMA); bf16: 3e-2 forward,
+    6e-2 gradients of the tensor's max (operands rounded to 8 mantissa bits; f32 accumulation and cell state)."""
+    tol_f, tol_g = (3e-2, 6e-2) if dt == "bf16" else (1e-4, 1e-4)
+    lstm, names, params, (out, hn_cat, xc), (hs_top, hnd, xcd) = _lstm_case(hb, B, T, I, Ic, H, L, dt, seed=B + H + T)
+    close(hs_top.transpose(0, 1), out, rtol=tol_f, what="hs_top")
+    close(hnd, hn_cat, rtol=tol_f, what="hn")
+    for p, n in zip(params, names):
+        close(p.grad, getattr(lstm, n).grad, rtol=tol_g, what="d" + n)
+    if Ic:
+        close(xcd.grad, xc.grad, rtol=tol_g, what="dxc")
+
+
+@pytest.mark.parametrize("I,Ic", [(80, 32), (80, 0), (0, 64)])
+def test_bench_shape_bf16_lstm_fwd_bwd_vs_torch_lstm(hb, I, Ic):
+    """B = 2048, H = 256, L = 2, T = 20, bf16: the three nets of the bench's model at the bench's batch, i.e. the persistent
+    forward kernel and the per-layer contraction-split backward kernel (with the fused from-above term) that the roofline
+    names, checked against the CPU oracle directly.  Forward 3e-2, gradients 6e-2 of each tensor's max; the relative
+    Frobenius error of every gradient is also bounded (1.5e-2): a wrong tile would pass a max-norm test on a large matrix."""
+    B, T, H, L = 2048, 20, 256, 2
+    lstm, names, params, (out, hn_cat, xc), (hs_top, hnd, xcd) = _lstm_case(hb, B, T, I, Ic, H, L, "bf16", seed=I + Ic)
+    assert hb.LAST_LSTM_FORM["form"] == 1, "expected the rows form of the persistent schedule at this shape"
+    close(hs_top.transpose(0, 1), out, rtol=3e-2, what="hs_top")
+    close(hnd, hn_cat, rtol=3e-2, what="hn")
+    pairs = [(p.grad, getattr(lstm, n).grad, "d" + n) for p, n in zip(params, names)]
+    if Ic:
+        pairs.append((xcd.grad, xc.grad, "dxc"))
+    for got, want, n in pairs:
+        close(got, want, rtol=6e-2, what=n)
+        g, w = got.detach().cpu().double(), want.detach().double()
+        rel = ((g - w).norm() / w.norm()).item()
+        assert rel < 1.5e-2, (n, rel)
+
+
+def test_simple_fhvae_z32_vs_oracle(hb):
+    """configs[0]: SimpleFHVAE(1600, 128/128, z1 = z2 = 32), 250 segments, 100-row table: all six outputs element-wise at
+    1e-4, the loss and every gradient (reference objective: decoder gradients are None) at 1e-4 of the tensor's max."""
+    from simple_fhvae import SimpleFHVAE
+    from train_model import loss_function
+
+    T, F, D, B, S = 20, 80, 32, 250, 100
+    torch.manual_seed(32)
+    ref = R.SimpleFHVAERef(T * F, [128, 128], [128, 128], D, D, [128, 128])
+    x, idx, ns = torch.randn(B, T, F), torch.randint(0, S, (B,)), torch.randint(20, 200, (B,))
+    table, e2, e1 = torch.randn(S, D, requires_grad=True), torch.randn(B, D), torch.randn(B, D)
+    for compat in (True, False):
+        m = SimpleFHVAE(T * F, [128, 128], [128, 128], D, D, [128, 128], reference_compat=compat)
+        m.load_state_dict(ref.state_dict(), strict=False)
+        m.cuda()
+        ref.zero_grad()
+        table.grad = None
+        want = ref(x, idx, S, ns, mu2_table=table, eps_z2=e2, eps_z1=e1, reference_compat=compat)
+        R.loss_function(want[0], want[1], 10.0).backward()
+        td = dev(table.detach()).requires_grad_(True)
+        got = m(dev(x), idx, S, ns, mu2_table=td, eps=(e2, e1))
+        for k, n in enumerate(OUT):
+            close_elementwise(got[k], want[k], what="%s (compat=%s)" % (n, compat))
+        loss = loss_function(got[0], got[1], 10.0)
+        close_elementwise(loss, R.loss_function(want[0], want[1], 10.0), what="loss")
+        loss.backward()
+        rp = dict(ref.named_parameters())
+        for n, p in m.named_parameters():
+            if n == "mu2_table":
+                continue
+            if rp[n].grad is None:
+                assert p.grad is None, n
+            else:
+                close(p.grad, rp[n].grad, what="grad " + n)
+        close(td.grad, table.grad, what="grad table")
+
+
+@pytest.mark.parametrize("cfg", [dict(T=40, F=80, H=256, D=32, B=32, S=300), dict(T=40, F=80, H=64, D=32, B=20, S=50)])
+def test_fhvae_t40_f32_vs_oracle(hb, cfg):
+    """configs[4]'s segment length (T = 40, input_size 3200) in f32 parity mode, end to end: outputs element-wise at 1e-4,
+    gradients (40 recurrent steps) at 5e-4 of each tensor's max."""
+    from fhvae import FHVAE
+    from train_model import loss_function
+
+    T, F, H, D, B, S = (cfg[k] for k in "TFHDBS")
+    torch.manual_seed(T + H)
+    ref = R.FHVAERef(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T)
+    m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T, reference_compat=False)
+    m.load_state_dict(ref.state_dict(), strict=False)
+    m.cuda()
+    x, idx, ns = torch.randn(B, T, F), torch.randint(0, S, (B,)), torch.randint(3, 100, (B,))
+    table, e2, e1 = torch.randn(S, D, requires_grad=True), torch.randn(B, D), torch.randn(B, D)
+    want = ref(x, idx, S, ns, mu2_table=table, eps_z2=e2, eps_z1=e1, reference_compat=False)
+    R.loss_function(want[0], want[1], 10.0).backward()
+    td = dev(table.detach()).requires_grad_(True)
+    got = m(dev(x), idx, S, ns, mu2_table=td, eps=(e2, e1))
+    for k, n in enumerate(OUT):
+        close_elementwise(got[k], want[k], what=n)
+    loss_function(got[0], got[1], 10.0).backward()
+    rp = dict(ref.named_parameters())
+    for n, p in m.named_parameters():
+        if n != "mu2_table":
+            close(p.grad, rp[n].grad, rtol=5e-4, what="grad " + n)
+    close(td.grad, table.grad, rtol=5e-4, what="grad table")
+
+
+def test_fhvae_h256_f32_outputs_elementwise(hb):
+    """The six forward outputs of the f32 LSTM model at the bench's model size (2x256, z = 32), element-wise at 1e-4."""
+    from fhvae import FHVAE
+
+    T, F, H, D, B, S = 20, 80, 256, 32, 96, 700
+    torch.manual_seed(77)
+    ref = R.FHVAERef(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T)
+    m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T, reference_compat=True)
+    m.load_state_dict(ref.state_dict(), strict=False)
+    m.cuda()
+    x, idx, ns = torch.randn(B, T, F), torch.randint(0, S, (B,)), torch.randint(3, 100, (B,))
+    table, e2, e1 = torch.randn(S, D), torch.randn(B, D), torch.randn(B, D)
+    with torch.no_grad():
+        want = ref(x, idx, S, ns, mu2_table=table, eps_z2=e2, eps_z1=e1, reference_compat=True)
+        got = m(dev(x), idx, S, ns, mu2_table=dev(table), eps=(e2, e1))
+    for k, n in enumerate(OUT):
+        close_elementwise(got[k], want[k], what=n)
+
+
+def test_fhvae_h512_bf16_tracks_f32_oracle(hb):
+    """configs[3]'s model (2x512, z = 32) in bf16 against the f32 oracle: "matched ELBO" tolerance 1e-2 on the outputs."""
+    from fhvae import FHVAE
+    from train_model import loss_function
+
+    T, F, H, D, B, S = 20, 80, 512, 32, 64, 500
+    torch.manual_seed(512)
+    ref = R.FHVAERef(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T)
+    m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T, reference_compat=False, compute_dtype="bf16")
+    m.load_state_dict(ref.state_dict(), strict=False)
+    m.cuda()
+    x, idx, ns = torch.randn(B, T, F), torch.randint(0, S, (B,)), torch.randint(3, 100, (B,))
+    table, e2, e1 = torch.randn(S, D), torch.randn(B, D), torch.randn(B, D)
+    with torch.no_grad():
+        want = ref(x, idx, S, ns, mu2_table=table, eps_z2=e2, eps_z1=e1, reference_compat=False)
+    td = dev(table).requires_grad_(True)
+    got = m(dev(x), idx, S, ns, mu2_table=td, eps=(e2, e1))
+    for k, n in enumerate(OUT):
+        close(got[k], want[k], rtol=1e-2, what=n)
+    loss_function(got[0], got[1], 10.0).backward()
+    torch.cuda.synchronize()
+    assert hb.lstm_sync_status() == 0
+    assert all(torch.isfinite(p.grad).all() for n, p in m.named_parameters() if n != "mu2_table")
+
+
+# ---------------------------------------------------------------------------------------------
+# K5 where training converges to: q ~ table[idx], large norms (the expanded MFMA form cancels there)
+# ---------------------------------------------------------------------------------------------
+def _disc_oracle_f64(q, table, idx):
+    """Direct (q - t)^2 form of simple_fhvae.py:119-122 in float64 (chunked over the table)."""
+    q64, t64 = q.double().requires_grad_(True), table.double().requires_grad_(True)
+    ce = R.disc_loss_chunked(q64, t64, idx, chunk=2048)
+    ce.backward()
+    return ce.detach(), q64.grad, t64.grad
+
+
+@pytest.mark.parametrize("B,S,scale,noise", [(256, 4600, 10.0, 1e-3), (2048, 4608, 10.0, 1e-3), (512, 9000, 3.0, 0.3),
+                                             (256, 4600, 1.0, 0.05)])
+def test_disc_converged_regime(hb, B, S, scale, noise):
+    """q = table[idx] + noise * N(0,1), table = scale * N(0,1), D = 32 (the f32-MFMA path: B*S >= 65536).  Oracle: the direct
+    form in float64.  Logits of the far rows are ~ -4 c scale^2 D (thousands), the target logit ~ -c noise^2 D (~0), and the
+    expanded form computes the latter as a difference of terms ~ c scale^2 D, so the ABSOLUTE error of a logit is
+    ~ 1e-7 * 2 c scale^2 D.  What must hold: CE to 1e-4 relative + 2e-3 absolute (CE itself can be ~1e-30 here: an absolute
+    floor of the logit's f32 resolution is the honest bound), gradients to 1e-3 of their max."""
+    torch.manual_seed(B + S)
+    D = 32
+    table = torch.randn(S, D) * scale
+    idx = torch.randint(0, S, (B,))
+    idx[1] = idx[0]
+    q = table[idx] + noise * torch.randn(B, D)
+    ce64, dq64, dt64 = _disc_oracle_f64(q, table, idx)
+    qd, td = dev(q).requires_grad_(True), dev(table).requires_grad_(True)
+    ce = hb.disc_lse(qd, td, dev(idx))
+    ce.backward()
+    resolution = 1.2e-7 * 2 * hb.INV_TWO_VAR * (scale * scale * D * 2)
+    assert abs(ce.item() - ce64.item()) <= 1e-4 * abs(ce64.item()) + max(2e-3, 4 * resolution), (ce.item(), ce64.item())
+    for got, want, n in ((qd.grad, dq64, "dq"), (td.grad, dt64, "dtable")):
+        err = (got.detach().cpu().double() - want).abs().max().item()
+        ref = max(want.abs().max().item(), 1e-6)
+        assert err <= 1e-3 * ref + 1e-6, (n, err, ref)
+    # the VALU (direct-form) kernels on the same inputs: they have no cancellation
+    import os
+
+    os.environ["FHVAE_DISC_VALU"] = "1"
+    try:
+        q2, t2 = dev(q).requires_grad_(True), dev(table).requires_grad_(True)
+        ce2 = hb.disc_lse(q2, t2, dev(idx))
+        ce2.backward()
+    finally:
+        os.environ.pop("FHVAE_DISC_VALU", None)
+    assert abs(ce2.item() - ce64.item()) <= 1e-4 * abs(ce64.item()) + 1e-5, (ce2.item(), ce64.item())
+    for got, want, n in ((q2.grad, dq64, "dq valu"), (t2.grad, dt64, "dtable valu")):
+        err = (got.detach().cpu().double() - want).abs().max().item()
+        assert err <= 1e-4 * max(want.abs().max().item(), 1e-6) + 1e-7, (n, err)

@@ -78,8 +78,49 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         U.load_checkpoint_file(tmp_path / "ref.tar", finetune=True)
 
-    class A:
-        dataset, data_format, feat_type, legacy, model_type, epochs, patience, alpha_dis = "timit", "numpy", "fbank", False, "fhvae", 100, 10, 10.0
-    assert U.create_training_strings(A)[2] == "timit_np_fbank_fhvae_e100_p10_a10.0"            # utils.py:20-42
     U.save_args(tmp_path, {"a": 1})
     assert U.load_args(tmp_path) == {"a": 1}
+
+
+def test_dataset_matches_independent_oracle(corpus):
+    """The package's host-side dataset against oracle/data_ref.py (an independent restatement of datasets.py's rules):
+    kept sequences, segment table, MVN statistics and every item."""
+    import datasets as D
+    from oracle.data_ref import CorpusRef
+
+    root, _ = corpus
+    ds = D.NumpyDataset(root / "feats.scp", root / "len.scp", min_len=20, mvn_path=str(root / "mvn_o.json"), seg_len=20, seg_shift=8)
+    ref = CorpusRef(root / "feats.scp", root / "len.scp", min_len=20, seg_len=20, seg_shift=8, mvn=True)
+    assert ds.seqlist == ref.keys and len(ds) == len(ref) and ds.num_segments == ref.num_segments
+    assert ds.seq_nsegs == ref.nseg.tolist()
+    assert [ds.seq2idx[s.seq] for s in ds.segs] == ref.seq_of.tolist() and [s.start for s in ds.segs] == ref.start.tolist()
+    np.testing.assert_array_equal(np.asarray(ds.mvn_params["mean"]), ref.mean)
+    np.testing.assert_array_equal(np.asarray(ds.mvn_params["std"]), ref.std)
+    for i in range(ds.num_segments):
+        a, b = ds[i], ref.item(i)
+        assert a[0] == b[0] and a[2] == b[2]
+        np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_reference_layout_checkpoint_fixture_loads(golden_dir):
+    """tests/golden/ref_checkpoint_simple_tiny.tar is a checkpoint in the reference's exact layout (utils.py:131-146: 5-value
+    model_params, plain state_dict, torch.optim.Adam state) written from the imported reference model by make_golden.py."""
+    import utils as U
+
+    f = os.path.join(golden_dir, "ref_checkpoint_simple_tiny.tar")
+    ck = torch.load(f, weights_only=False)
+    assert set(ck) == {"best_val_lb", "best_epoch", "epoch", "model_type", "model_params", "optimizer", "state_dict",
+                       "summary_vals", "values"} and len(ck["model_params"]) == 5
+    with pytest.raises(ValueError):
+        U.load_checkpoint_file(f, finetune=False)  # the reference stores no input size (utils.py:135-141)
+    m, values, optim_state, start_epoch, best_val_lb, summary = U.load_checkpoint_file(f, finetune=False, input_size=32)
+    assert type(m).__name__ == "SimpleFHVAE" and m.mu2_table is None and start_epoch == 4 and summary is None
+    assert values == ck["values"] and best_val_lb == ck["best_val_lb"]
+    sd = m.state_dict()
+    assert list(sd) == list(ck["state_dict"])  # same keys, same order
+    for k, v in ck["state_dict"].items():
+        assert torch.equal(sd[k], v), k
+    # the reference's Adam state: 24 parameters in the group, moments for the 16 that had a gradient (decoder detached)
+    assert len(optim_state["param_groups"][0]["params"]) == 24 and len(optim_state["state"]) == 16
+    m2, _, o2, e2, _, _ = U.load_checkpoint_file(f, finetune=True, input_size=32)
+    assert o2 is None and e2 is None

@@ -3,6 +3,7 @@ gradient buckets and both fused-Adam arenas are the product code): the data-para
 the single-process run on the global batch."""
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -46,8 +47,23 @@ def _worker(rank, world, port, ret):
     fwd = m.forward
     m.forward = lambda *a, **k: fwd(*a, eps=(e2[sl].cuda(), e1[sl].cuda()), **k)
     losses = [runner.train_step(x[sl].cuda(), idx[sl].cuda(), ns[sl].cuda(), alpha=10.0)[0].item() for _ in range(3)]
+    full = runner.state_dict()  # collective: gathers the table shards and their Adam moments (checkpoint path)
+    n_par = len(full["param_names"])
     ret[rank] = dict(losses=losses, rows=(runner.sh.row0, runner.sh.row1), shard=runner.shard.detach().cpu(),
-                     w=m.z2_pre_encoder.lstm.weight_hh_l1.detach().cpu(), wd=m.pre_decoder.lstm.weight_ih_l0.detach().cpu())
+                     w=m.z2_pre_encoder.lstm.weight_hh_l1.detach().cpu(), wd=m.pre_decoder.lstm.weight_ih_l0.detach().cpu(),
+                     status=runner.check_status(), table=full["state_dict"]["mu2_table"].cpu(),
+                     table_m=full["optimizer"]["state"][n_par - 1]["exp_avg"].cpu(),
+                     w_m=full["optimizer"]["state"][full["param_names"].index("z2_pre_encoder.lstm.weight_hh_l1")]["exp_avg"].cpu(),
+                     step=float(full["optimizer"]["state"][0]["step"]), names=full["param_names"])
+    # re-shard: a fresh runner loaded from the gathered state continues identically
+    m2 = _build()
+    r2 = DistributedFHVAE(m2, lr=1e-3, betas=(0.95, 0.999))
+    r2.load_state_dict(full)
+    f2 = m2.forward
+    m2.forward = lambda *a, **k: f2(*a, eps=(e2[sl].cuda(), e1[sl].cuda()), **k)
+    la = runner.train_step(x[sl].cuda(), idx[sl].cuda(), ns[sl].cuda(), alpha=10.0)[0].item()
+    lb = r2.train_step(x[sl].cuda(), idx[sl].cuda(), ns[sl].cuda(), alpha=10.0)[0].item()
+    ret[rank] = dict(ret[rank], resumed=(la, lb), resumed_shard_equal=bool(torch.allclose(runner.shard, r2.shard, rtol=1e-4, atol=1e-5)))
     dist.destroy_process_group()
 
 
@@ -81,3 +97,47 @@ def test_two_ranks_one_gpu_match_single_process_global_batch():
         torch.testing.assert_close(ret[r]["shard"], table[a:b], rtol=2e-4, atol=1e-4)
         torch.testing.assert_close(ret[r]["w"], m.z2_pre_encoder.lstm.weight_hh_l1.detach().cpu(), rtol=2e-4, atol=1e-4)
         torch.testing.assert_close(ret[r]["wd"], m.pre_decoder.lstm.weight_ih_l0.detach().cpu(), rtol=2e-4, atol=1e-4)
+        assert ret[r]["status"] == 0
+        # checkpoint path: the gathered table is the concatenation of the shards; layout = the single-GPU optimizer's
+        assert torch.equal(ret[r]["table"][a:b], ret[r]["shard"]) and ret[r]["table"].shape == (S, D)
+        la, lb = ret[r]["resumed"]
+        assert la == lb and ret[r]["resumed_shard_equal"], ret[r]["resumed"]
+    assert torch.equal(ret[0]["table"], ret[1]["table"])
+    sd1 = opt.state_dict()
+    names1 = [n for n, _ in m.named_parameters()]
+    assert ret[0]["names"] == names1 and ret[0]["step"] == 3.0 == float(sd1["state"][0]["step"])
+    torch.testing.assert_close(ret[0]["table_m"], sd1["state"][len(names1) - 1]["exp_avg"].cpu(), rtol=2e-3, atol=1e-6)
+    torch.testing.assert_close(ret[0]["w_m"], sd1["state"][names1.index("z2_pre_encoder.lstm.weight_hh_l1")]["exp_avg"].cpu(),
+                               rtol=2e-3, atol=1e-7)
+
+
+def _worker_tiny_table(rank, world, port, ret):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "pytorch-scalablefhvae_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dist_shard import DistributedFHVAE
+    from fhvae import FHVAE
+
+    torch.manual_seed(11)
+    S2 = 2  # fewer rows than ranks: the last rank's shard is empty
+    m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], num_seqs=S2, reference_compat=False).cuda()
+    runner = DistributedFHVAE(m, lr=1e-3, betas=(0.95, 0.999))
+    g = torch.Generator().manual_seed(100 + rank)
+    x, idx, ns = torch.randn(8, T, F, generator=g).cuda(), torch.randint(0, S2, (8,), generator=g).cuda(), torch.randint(20, 200, (8,), generator=g).cuda()
+    losses = [runner.train_step(x, idx, ns, alpha=10.0)[0].item() for _ in range(2)]
+    ret[rank] = dict(losses=losses, rows=(runner.sh.row0, runner.sh.row1), table=runner.gather_table().cpu(), status=runner.check_status())
+    dist.destroy_process_group()
+
+
+def test_empty_shard_rank_takes_part():
+    """3 ranks, a 2-row table: rank 2 owns no rows (FH_CHECK_POS(S) / n = 0 crashed it)."""
+    world = 3
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_tiny_table, args=(world, 29900 + os.getpid() % 90, ret), nprocs=world, join=True)
+    assert [ret[r]["rows"] for r in range(world)] == [(0, 1), (1, 2), (2, 2)]
+    for r in range(world):
+        assert all(np.isfinite(ret[r]["losses"])) and ret[r]["status"] == 0 and ret[r]["table"].shape == (2, D)
+        assert torch.equal(ret[r]["table"], ret[0]["table"])

@@ -30,6 +30,32 @@ def test_resident_pool_matches_dataset_getitem(hb, corpus):
     assert seen == len(pool)
 
 
+def test_segment_gather_matches_independent_oracle(hb, corpus):
+    """fhvae_segment_gather (through ResidentSegmentPool) against oracle/data_ref.py -- NOT against the package's own
+    NumpyDataset: indices, features (MVN fused in the kernel: (x - mean) * (1/std), 1 ulp of the divide form) and counts."""
+    import datasets as D
+    from oracle.data_ref import CorpusRef
+
+    root, _ = corpus
+    for mvn in (True, False):
+        ds = D.NumpyDataset(root / "feats.scp", root / "len.scp", min_len=20, mvn_path=str(root / "mvn_g.json") if mvn else None,
+                            seg_len=20, seg_shift=8)
+        ref = CorpusRef(root / "feats.scp", root / "len.scp", min_len=20, seg_len=20, seg_shift=8, mvn=mvn)
+        pool = D.ResidentSegmentPool(ds)
+        assert len(pool) == ref.num_segments
+        ids = torch.arange(len(pool) - 1, -1, -1, device="cuda")  # every segment, reversed order
+        idxs, x, nsegs = pool.batch(ids)
+        want_i, want_x, want_n = ref.batch(ids.tolist())
+        assert idxs.cpu().tolist() == want_i.tolist() and nsegs.cpu().tolist() == want_n.tolist()
+        if mvn:
+            close(x, torch.from_numpy(want_x), rtol=2e-6, what="segments (mvn)")
+        else:
+            assert torch.equal(x.cpu(), torch.from_numpy(want_x)), "raw segments must be bit-exact copies"
+        # an epoch covers every segment exactly once
+        seen = torch.cat([b[0] for b in pool.epoch(5, shuffle=True)]).cpu()
+        assert sorted(seen.tolist()) == sorted(want_i.tolist())
+
+
 def test_mu2_estimate_and_estimate_mu2_dict(hb):
     import utils as U
     from fhvae import FHVAE
@@ -92,7 +118,7 @@ def test_train_model_main_real_scp_and_synthetic(hb, corpus, tmp_path, capsys):
     rc = TM.main(["--train-feat-scp", str(root / "feats.scp"), "--train-len-scp", str(root / "len.scp"), "--mvn-path",
                   str(root / "mvn2.json"), "--z1-hus", "16", "16", "--z2-hus", "16", "16", "--x-hus", "16", "16", "--z1-dim", "8",
                   "--z2-dim", "8", "--epochs", "2", "--training-batch-size", "8", "--exp-dir", str(exp), "--hierarchical",
-                  "--paper-objective"])
+                  ])
     out = capsys.readouterr().out
     assert rc == 0 and "Training complete!" in out and "hierarchical: mu2 re-estimated for 3 of 3" in out
     m = U.load_checkpoint_file(exp / "fhvae_run_e1.tar", finetune=True)[0]
