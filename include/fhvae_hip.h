@@ -138,9 +138,9 @@ typedef struct fhvae_lstm_desc {
                     copies of x, xc, the weights and the transposed weights, the backward reuses it.  It also
                     holds the persistent schedules' sync block (first FHVAE_LSTM_SYNC_BYTES) and their exchange
                     buffer (2*L*B*4H bf16): keep it alive and untouched between the forward and its backward */
-  int32_t* sticky_status; /* BF16 mode, optional (may be NULL): int32 device word that is never cleared by the library.  Every
-                    forward ORs the status word its workspace held (the previous forward/backward on it) into it before
-                    re-arming the sync block, so a launch that gave up stays visible however late the host looks. */
+  int32_t* sticky_status; /* BF16 mode, optional (may be NULL): int32 device word that the library never clears.  A persistent
+                    launch that gives up ORs its status code into it as well as into the workspace's status word (which
+                    the next forward on that workspace re-arms): the failure stays visible however late the host looks. */
 } fhvae_lstm_desc;
 
 int64_t fhvae_lstm_lp_bytes(const fhvae_lstm_desc* d);
@@ -174,6 +174,17 @@ typedef struct fhvae_lstm_bwd_desc {
 } fhvae_lstm_bwd_desc;
 
 int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* d, void* stream);
+/* Phase 2 of n backward passes at once (their phase 1 must have been enqueued on `stream` before): the weight / bias
+ * gradients of several nets.  In BF16 mode the long contractions dW[4H,.] += dgates^T . [x | h] over the T*B rows of ALL the
+ * descriptors run as ONE grouped launch (csrc/wgrad.hip); the host defers them to the end of the backward pass, where the
+ * three nets of the model together fill the chip with whole tiles and few K slices. */
+int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* descs, int n, void* stream);
+/* The contraction itself: C[M,N] (f32, ldc) += A[K,M]^T . B[K,N], bf16 operands whose ROW index is the contraction index
+ * (lda, ldb in elements, multiples of 8; 16-byte aligned bases; K*ld*2 < 2^30) -- dW += dY^T X of a linear / LSTM layer over
+ * K = batch x time rows (autograd of nn.Linear, simple_fhvae.py:127-134; of the LSTM body missing at fhvae.py:14).
+ * FHVAE_ERR_ALIGN when the preconditions do not hold. */
+int fhvae_wgrad_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc, int64_t M,
+                     int64_t N, int64_t K, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * mu2 gather (K4): mu2[b,:] = table[idx[b],:]  -- torch.gather, simple_fhvae.py:53.

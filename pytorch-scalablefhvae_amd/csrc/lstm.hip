@@ -15,6 +15,8 @@
 // pre-activations never touch HBM.
 #include "gemm_launch.h"
 #include "lstm_cluster.h"
+#include "wgrad.h"
+#include <vector>
 #include "trace.h"
 #include <cstdlib>
 
@@ -269,7 +271,7 @@ struct CastItem {
 };
 struct CastBatch {
   unsigned* sync;  // the workspace's sync block (lstm_cluster.h): cleared here, once per forward
-  int* sticky;     // fhvae_lstm_desc.sticky_status: the block's old status word is ORed into it first
+  int* sticky;     // fhvae_lstm_desc.sticky_status: its address is left in the block for cluster_give_up
   int n;
   CastItem it[4 * FHVAE_MAX_LAYERS + 2];
 };
@@ -278,11 +280,10 @@ struct CastBatch {
 __global__ __launch_bounds__(256) void cast_batch_kernel(CastBatch cb) {
   __shared__ u16 tile[32][33];
   if (blockIdx.x == 0 && blockIdx.y == 0) {
-    if (threadIdx.x == 0 && cb.sticky) {  // (thread 0 also clears word 0 below: program order keeps the read first)
-      const unsigned old = cb.sync[kSyncStatus];
-      if (old) atomicOr(cb.sticky, (int)old);
-    }
-    for (int i = threadIdx.x; i < kSyncWordsUsed; i += blockDim.x) cb.sync[i] = 0u;
+    // words kSyncSticky, +1 carry the address of the caller's sticky status word: a launch that gives up ORs its code into it
+    // as well (cluster_give_up), so the failure stays visible after this block is re-armed by the next forward
+    for (int i = threadIdx.x; i < kSyncWordsUsed; i += blockDim.x)
+      cb.sync[i] = i == kSyncSticky ? (unsigned)((uintptr_t)cb.sticky & 0xffffffffu) : i == kSyncSticky + 1 ? (unsigned)((uintptr_t)cb.sticky >> 32) : 0u;
   }
   const CastItem& c = cb.it[blockIdx.y];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -628,8 +629,12 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
 // weight / bias / input gradients after the recurrence.  The long contractions (over T*B rows) run in
 // the operand dtype (KM/KM: bf16 uses transposed LDS reads); the time-constant-input part (B rows) and
 // d_xc stay f32 (f32 dgsum).
+constexpr int64_t kWgradMinK = 1024;  // shorter contractions stay on the generic engine (grouped 64x64 tiles)
+
+// `wq` (bf16 only): long contractions that meet wgrad.hip's preconditions are appended to it instead of being launched; the
+// caller launches everything it has collected (possibly from several nets) as one grouped launch (launch_wgrad).
 template <typename T>
-static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStream_t st) {
+static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStream_t st, std::vector<WgProblem>* wq = nullptr) {
   const fhvae_lstm_desc* d = &bd->f;
   const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
   const int L = d->L;
@@ -640,6 +645,17 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
   // (at small batches each is a latency-bound launch of a few workgroups)
   GemmParams grp[2 * FHVAE_MAX_LAYERS];
   int ng = 0;
+  // -> true: taken by the dedicated long-K kernel (queued in wq)
+  auto wgrad_long = [&](const void* a, int64_t lda, const void* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc, int64_t Ncols) {
+    if (!wq || sizeof(T) != 2 || Kc < kWgradMinK) return false;
+    WgProblem w = {};
+    w.A = (const u16*)a, w.B = (const u16*)b, w.C = c;
+    w.lda = lda, w.ldb = ldb, w.ldc = ldc;
+    w.M = (int)G, w.N = (int)Ncols, w.K = (int)Kc;
+    if (!wgrad_eligible(w)) return false;
+    wq->push_back(w);
+    return true;
+  };
   auto wgrad = [&](const void* a, int64_t lda, const void* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc, int64_t Ncols) {
     GemmParams p = {};
     p.seg[0] = Seg{a, lda, 0, b, ldb, 0, (int)Kc, 0};
@@ -661,12 +677,15 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
     const T* dgl = dg + (int64_t)l * T_ * B * G;
     const T* hl = hs + (int64_t)l * T_ * B * H;
     int e;
-    if (bd->dw_hh[l] && T_ > 1) grp[ng++] = wgrad(dgl + B * G, G, hl, H, (T_ - 1) * B, bd->dw_hh[l], H, H);
+    if (bd->dw_hh[l] && T_ > 1 && !wgrad_long(dgl + B * G, G, hl, H, (T_ - 1) * B, bd->dw_hh[l], H, H))
+      grp[ng++] = wgrad(dgl + B * G, G, hl, H, (T_ - 1) * B, bd->dw_hh[l], H, H);
     if (bd->dw_ih[l]) {
       if (l > 0) {
-        grp[ng++] = wgrad(dgl, G, hs + (int64_t)(l - 1) * T_ * B * H, H, T_ * B, bd->dw_ih[l], H, H);
+        if (!wgrad_long(dgl, G, hs + (int64_t)(l - 1) * T_ * B * H, H, T_ * B, bd->dw_ih[l], H, H))
+          grp[ng++] = wgrad(dgl, G, hs + (int64_t)(l - 1) * T_ * B * H, H, T_ * B, bd->dw_ih[l], H, H);
       } else {
-        if (I > 0) grp[ng++] = wgrad(dgl, G, op.x, I, T_ * B, bd->dw_ih[0], K0, I);
+        if (I > 0 && !wgrad_long(dgl, G, op.x, I, T_ * B, bd->dw_ih[0], K0, I))
+          grp[ng++] = wgrad(dgl, G, op.x, I, T_ * B, bd->dw_ih[0], K0, I);
         if (Ic > 0) {  // the time-constant input's part: f32 running sum over t of dg (B rows)
           GemmParams p = wgrad(bd->dgsum, G, d->xc, Ic, B, bd->dw_ih[0] + I, K0, Ic);
           e = launch_gemm(p, FHVAE_F32, st);
@@ -736,5 +755,36 @@ extern "C" int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* bd, void* stream) {
     e = lstm_dxc(bd, st);
     if (e) return e;
   }
-  return par ? lstm_param_grads<u16>(bd, op, st) : FHVAE_OK;
+  if (!par) return FHVAE_OK;
+  std::vector<WgProblem> wq;
+  e = lstm_param_grads<u16>(bd, op, st, getenv("FHVAE_NO_WGRAD") ? nullptr : &wq);
+  if (e) return e;
+  return launch_wgrad(wq.data(), (int)wq.size(), st);
+}
+
+// Phase 2 (parameter gradients) of n backward passes whose recurrences (phase 1) have run: the long weight-gradient
+// contractions of ALL of them go out as one grouped launch of wgrad.hip's kernel (one workgroup per CU, the K slices being
+// what is left after the tiles: 3 nets = 36 tiles x 7 slices instead of 12 launches x 512 workgroups of split-K atomics).
+extern "C" int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* bds, int n, void* stream) {
+  FH_CHECK_PTR(bds);
+  if (n < 0) return FHVAE_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<WgProblem> wq;
+  const bool use_wq = !getenv("FHVAE_NO_WGRAD");
+  for (int i = 0; i < n; ++i) {
+    const fhvae_lstm_bwd_desc* bd = bds[i];
+    FH_CHECK_PTR(bd);
+    const fhvae_lstm_desc* d = &bd->f;
+    int e = check_desc(d);
+    if (e) return e;
+    FH_CHECK_PTR(bd->dgates);
+    if (d->Ic > 0) FH_CHECK_PTR(bd->dgsum);
+    if (d->dtype == FHVAE_F32) {
+      e = lstm_param_grads<float>(bd, ops_f32(d), st);
+    } else {
+      e = lstm_param_grads<u16>(bd, ops_bf16(d), st, use_wq ? &wq : nullptr);
+    }
+    if (e) return e;
+  }
+  return launch_wgrad(wq.data(), (int)wq.size(), st);
 }

@@ -6,6 +6,7 @@ namespace fh {
 
 // The first FHVAE_LSTM_SYNC_BYTES of the bf16 workspace (fhvae_lstm_desc.lp) are the kernels' sync block (u32 words):
 constexpr int kSyncStatus = 0;    // 0 = ok; bit 0: a bounded spin gave up, bit 1: a workgroup could not read its XCD
+constexpr int kSyncSticky = 2;    // two words: address of fhvae_lstm_desc.sticky_status (0 = none), written when the block is armed
 constexpr int kSyncXcdCnt = 16;   // 8 arrival counters (one per XCD): ticket & 31 = a workgroup's slot on its XCD, ticket >> 5 = the launch
 constexpr int kSyncFlags = 64;    // + cluster * 32: one word per workgroup of the cluster = the last step it has published
 constexpr int kSyncWordsUsed = kSyncFlags + 64 * 32;

@@ -56,6 +56,15 @@ __device__ __forceinline__ unsigned xcc_id() {
   return v & 0xf;
 }
 
+// a launch gives up: the code goes into the block's status word (the other workgroups watch it and leave) and into the
+// caller's sticky word (fhvae_lstm_desc.sticky_status), which no later forward clears
+__device__ __forceinline__ void cluster_give_up(unsigned* sync, unsigned code) {
+  __hip_atomic_fetch_or(sync + kSyncStatus, code, RLX_AGENT);
+  const unsigned long long a = (unsigned long long)__hip_atomic_load(sync + kSyncSticky, RLX_AGENT) |
+                               ((unsigned long long)__hip_atomic_load(sync + kSyncSticky + 1, RLX_AGENT) << 32);
+  if (a) __hip_atomic_fetch_or((unsigned*)a, code, RLX_AGENT);
+}
+
 // Slot of this workgroup on its XCD and the number of this launch on the sync block: (launch << 8) | (x * 32 + slot), or -1
 // (abort).  An XCD's counter hands out 32 tickets per launch (256 workgroups, 32 per XCD), so ticket / 32 IS the launch number:
 // the host does not have to count launches, and the backward needs no re-arming of the block after the forward.  (If an XCD ever
@@ -69,7 +78,7 @@ __device__ __forceinline__ int cluster_join(unsigned* sync, int* s_word) {
       const unsigned ticket = __hip_atomic_fetch_add(sync + kSyncXcdCnt + x, 1u, RLX_AGENT);
       v = (int)(((ticket >> 5) << 8) | (x * 32 + (ticket & 31u)));
     }
-    if (v < 0) __hip_atomic_fetch_or(sync + kSyncStatus, 2u, RLX_AGENT);
+    if (v < 0) cluster_give_up(sync, 2u);
     s_word[0] = v;
   }
   __syncthreads();
@@ -87,7 +96,7 @@ __device__ __forceinline__ bool cluster_wait(unsigned* sync, const unsigned* fla
     if (__any(st != 0)) return false;
     if (__all(v >= epoch)) break;
     if (spins > kSpinLimit) {
-      if (lane == 0) __hip_atomic_fetch_or(sync + kSyncStatus, 1u, RLX_AGENT);
+      if (lane == 0) cluster_give_up(sync, 1u);
       return false;
     }
   }

@@ -308,24 +308,27 @@ class DistributedFHVAE:
         never on the training step)."""
         return self._gather_rows(self.shard.data)
 
+    def _named_net_params(self):
+        return [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+
     def state_dict(self) -> dict:
         """Single-GPU-compatible state: the model's state_dict with the gathered `mu2_table`, and one Adam state in
-        torch.optim.Adam's layout over (net parameters in model.named_parameters() order ..., mu2_table) -- what
-        FusedAdam(model.parameters()).state_dict() holds on one GPU.  Collective: call on every rank."""
+        torch.optim.Adam's layout over the parameters in the order model.named_parameters() has on ONE GPU (the module's own
+        `mu2_table` first, then the nets) -- what FusedAdam(model.parameters()).state_dict() holds there.
+        Collective: call on every rank."""
         sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
         sd["mu2_table"] = self.gather_table()
         nets = self.opt_nets.state_dict()
         tab = self.opt_table.state_dict()
-        names = [n for n, p in self.model.named_parameters() if p.requires_grad]
-        order = {id(p): i for i, p in enumerate(self.opt_nets._params)}
-        state = {}
-        for j, n in enumerate(names):
-            state[j] = nets["state"][order[id(dict(self.model.named_parameters())[n])]]
+        named = self._named_net_params()
+        slot = {id(p): i for i, p in enumerate(self.opt_nets._params)}
         t = tab["state"][0]
-        state[len(names)] = {"step": t["step"], "exp_avg": self._gather_rows(t["exp_avg"]),
-                             "exp_avg_sq": self._gather_rows(t["exp_avg_sq"])}
-        groups = [dict(nets["param_groups"][0], params=list(range(len(names) + 1)))]
-        return {"state_dict": sd, "optimizer": {"state": state, "param_groups": groups}, "param_names": names + ["mu2_table"]}
+        state = {0: {"step": t["step"], "exp_avg": self._gather_rows(t["exp_avg"]), "exp_avg_sq": self._gather_rows(t["exp_avg_sq"])}}
+        for j, (n, p) in enumerate(named):
+            state[j + 1] = nets["state"][slot[id(p)]]
+        groups = [dict(nets["param_groups"][0], params=list(range(len(named) + 1)))]
+        return {"state_dict": sd, "optimizer": {"state": state, "param_groups": groups},
+                "param_names": ["mu2_table"] + [n for n, _ in named]}
 
     def load_state_dict(self, full: dict):
         """Inverse of state_dict(): every rank passes the same full state and keeps its own rows."""
@@ -337,14 +340,13 @@ class DistributedFHVAE:
             self.shard.data.copy_(table[sh.row0:sh.row1].to(self.shard.device))
         opt = full.get("optimizer")
         if opt is not None:
-            names = [n for n, p in self.model.named_parameters() if p.requires_grad]
-            by_name = dict(self.model.named_parameters())
-            pos = {id(by_name[n]): j for j, n in enumerate(names)}
+            named = self._named_net_params()
+            pos = {id(p): j + 1 for j, (_, p) in enumerate(named)}
             st = opt["state"]
             nets_state = {i: st[pos[id(p)]] for i, p in enumerate(self.opt_nets._params) if pos[id(p)] in st}
             g = dict(opt["param_groups"][0])
             self.opt_nets.load_state_dict({"state": nets_state, "param_groups": [dict(g, params=list(range(len(self.opt_nets._params))))]})
-            t = st.get(len(names))
+            t = st.get(0)
             if t is not None:
                 rows = {"step": t["step"], "exp_avg": t["exp_avg"][sh.row0:sh.row1], "exp_avg_sq": t["exp_avg_sq"][sh.row0:sh.row1]}
                 self.opt_table.load_state_dict({"state": {0: rows}, "param_groups": [dict(g, params=[0])]})

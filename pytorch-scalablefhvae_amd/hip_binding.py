@@ -89,6 +89,8 @@ SIGNATURES = {
     "fhvae_lstm_form": (C.c_int, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
     "fhvae_lstm_seq_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), _vp]),
+    "fhvae_lstm_param_grads_multi": (C.c_int, [C.POINTER(C.POINTER(LstmBwdDesc)), C.c_int, _vp]),
+    "fhvae_wgrad_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
     "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     "fhvae_mu2_gather_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp]),
     "fhvae_disc_lse_rescale": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
@@ -146,6 +148,36 @@ _SIDE = {"stream": None, "pending": False, "keep": [], "enabled": False}
 #: start the all-reduce of a net's gradient bucket while the next net's backward recurrence still runs
 LSTM_BWD_REC_HOOK = {"fn": None}  # fn(sinks): fired between a net's backward recurrence and its parameter gradients
 LSTM_BWD_DONE_HOOK = {"fn": None}
+
+
+# ---------------------------------------------------------------------------------------------
+# Deferred parameter gradients.  The weight gradients of an LSTM net depend only on what its backward recurrence left
+# (dgates) and on saved states; nothing on the rest of the backward pass depends on them.  When every parameter has a
+# gradient sink (hip_optim.FusedAdam's flat arena) the backward of a net therefore only runs its recurrence and QUEUES its
+# parameter-gradient phase; the optimizer (step / flat_grad / zero_grad) flushes the queue as ONE grouped call
+# (fhvae_lstm_param_grads_multi): the 12 long weight-gradient contractions of the three nets become one launch of whole
+# 256x256 tiles with a few K slices instead of 12 launches of 512 split-K workgroups each.
+# A caller that reads `param.grad` between backward() and the optimizer must call flush_param_grads() first.
+# ---------------------------------------------------------------------------------------------
+_DEFER = {"enabled": not os.environ.get("FHVAE_NO_DEFER"), "pending": []}
+
+
+def flush_param_grads():
+    """Run the queued parameter-gradient phases (current stream).  No-op when nothing is queued."""
+    pend = _DEFER["pending"]
+    if not pend:
+        return
+    lib = load_library()
+    n = len(pend)
+    arr = (C.POINTER(LstmBwdDesc) * n)(*[C.pointer(bd) for bd, _ in pend])
+    with _Timed("fhvae_lstm_param_grads_multi"):
+        _check(lib.fhvae_lstm_param_grads_multi(arr, n, _stream()), "fhvae_lstm_param_grads_multi")
+    pend.clear()  # (the caching allocator keeps the released buffers ordered behind this stream's queued work)
+
+
+def set_defer_param_grads(on: bool):
+    flush_param_grads()
+    _DEFER["enabled"] = bool(on)
 
 
 def side_stream():
@@ -635,6 +667,13 @@ class _LstmSeq(torch.autograd.Function):
         bd.d_xc = _p(d_xc)
         ws_below = torch.empty(T, B, H, **f32) if (ctx.dtype == BF16 and L > 1) else None
         bd.ws_below = _p(ws_below)
+        if (_DEFER["enabled"] and not _SIDE["enabled"] and all(sk is not None for sk in ctx.sinks)):
+            # recurrence now; the parameter gradients with those of the other nets at the optimizer (flush_param_grads)
+            bd.phase = 1
+            with _Timed("fhvae_lstm_seq_bwd"):
+                _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
+            _DEFER["pending"].append((bd, (x_tm, xc, hs, cs, gates, lp, pre, dgates, dgsum, dc, d_hs_top, d_hn, params, ctx.x_lp)))
+            return (None, d_xc, None, None, None, *[None] * len(params))
         if _SIDE["enabled"] and all(sk is not None for sk in ctx.sinks):
             # recurrence on this stream; the weight-gradient contractions on the side stream, joined by the optimizer
             bd.phase = 1
@@ -882,6 +921,19 @@ class _DiscLse(torch.autograd.Function):
 
 def disc_lse(q, table, idx):
     return _DiscLse.apply(q, table, idx)
+
+
+def wgrad_bf16_(c, a, b):
+    """c[M,N] (f32) += a[K,M]^T . b[K,N] for bf16 a, b whose rows are the contraction index (fhvae_wgrad_bf16)."""
+    lib = load_library()
+    _need_gpu(c, a, b)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and c.dtype == torch.float32
+    assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1 and a.shape[0] == b.shape[0]
+    K, M = a.shape
+    N = b.shape[1]
+    with _Timed("fhvae_wgrad_bf16"):
+        _check(lib.fhvae_wgrad_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), M, N, K, _stream()), "fhvae_wgrad_bf16")
+    return c
 
 
 def adam_step_(p, g, m, v, step_dev, lr, beta1, beta2, eps, grad_scale=1.0, p_lp=None):

@@ -93,6 +93,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = False):
         # keep the arena views attached (set_to_none would detach them); one memset for everything
+        hb.flush_param_grads()  # (a backward that was never followed by step(): its queued kernels must not land after the memset)
         hb.join_side_stream()
         self.g_arena.flat.zero_()
         for p, gv in zip(self._params, self.g_arena.views):
@@ -100,11 +101,13 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad = gv
 
     def flat_grad(self) -> torch.Tensor:
+        hb.flush_param_grads()  # the nets' deferred weight-gradient contractions: one grouped launch
         hb.join_side_stream()  # weight-gradient GEMMs may still be running on the side stream
         return self.g_arena.flat
 
     @torch.no_grad()
     def step(self, closure=None):
+        hb.flush_param_grads()
         hb.join_side_stream()
         for p, gv in zip(self._params, self.g_arena.views):
             if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():

@@ -48,13 +48,12 @@ def _worker(rank, world, port, ret):
     m.forward = lambda *a, **k: fwd(*a, eps=(e2[sl].cuda(), e1[sl].cuda()), **k)
     losses = [runner.train_step(x[sl].cuda(), idx[sl].cuda(), ns[sl].cuda(), alpha=10.0)[0].item() for _ in range(3)]
     full = runner.state_dict()  # collective: gathers the table shards and their Adam moments (checkpoint path)
-    n_par = len(full["param_names"])
     ret[rank] = dict(losses=losses, rows=(runner.sh.row0, runner.sh.row1), shard=runner.shard.detach().cpu(),
                      w=m.z2_pre_encoder.lstm.weight_hh_l1.detach().cpu(), wd=m.pre_decoder.lstm.weight_ih_l0.detach().cpu(),
                      status=runner.check_status(), table=full["state_dict"]["mu2_table"].cpu(),
-                     table_m=full["optimizer"]["state"][n_par - 1]["exp_avg"].cpu(),
+                     table_m=full["optimizer"]["state"][0]["exp_avg"].cpu(),
                      w_m=full["optimizer"]["state"][full["param_names"].index("z2_pre_encoder.lstm.weight_hh_l1")]["exp_avg"].cpu(),
-                     step=float(full["optimizer"]["state"][0]["step"]), names=full["param_names"])
+                     step=float(full["optimizer"]["state"][1]["step"]), names=full["param_names"])
     # re-shard: a fresh runner loaded from the gathered state continues identically
     m2 = _build()
     r2 = DistributedFHVAE(m2, lr=1e-3, betas=(0.95, 0.999))
@@ -106,7 +105,7 @@ def test_two_ranks_one_gpu_match_single_process_global_batch():
     sd1 = opt.state_dict()
     names1 = [n for n, _ in m.named_parameters()]
     assert ret[0]["names"] == names1 and ret[0]["step"] == 3.0 == float(sd1["state"][0]["step"])
-    torch.testing.assert_close(ret[0]["table_m"], sd1["state"][len(names1) - 1]["exp_avg"].cpu(), rtol=2e-3, atol=1e-6)
+    torch.testing.assert_close(ret[0]["table_m"], sd1["state"][names1.index("mu2_table")]["exp_avg"].cpu(), rtol=2e-3, atol=1e-6)
     torch.testing.assert_close(ret[0]["w_m"], sd1["state"][names1.index("z2_pre_encoder.lstm.weight_hh_l1")]["exp_avg"].cpu(),
                                rtol=2e-3, atol=1e-7)
 

@@ -123,6 +123,59 @@ def test_lstm_seq_vs_torch_lstm(hb, B, T, I, Ic, H, L, dt):
     print("lstm %s B=%d H=%d: fwd max-rel %.2e, worst grad max-rel %.2e" % (dt, B, H, _max_rel(hnd, hn_cat), worst))
 
 
+@pytest.mark.parametrize("K,M,N", [(40960, 1024, 256), (1280, 512, 80), (5000, 192, 112), (777, 1024, 256), (8192, 2048, 512),
+                                   (64, 256, 256), (4096 + 8, 320, 136)])
+def test_wgrad_bf16_vs_cpu_matmul(hb, K, M, N):
+    """fhvae_wgrad_bf16: C += A^T B over K rows (csrc/wgrad.hip: 256x256 / 256x128 tiles, LDS-DMA double buffer, hardware
+    transposed fragment reads, split-K atomics), K tails / ragged M, N / odd slice counts included, against the f32 CPU matmul
+    of the same bf16 operands.  f32 accumulation in a different order: 2e-5 of the output's scale sqrt(K)."""
+    torch.manual_seed(K + M)
+    # padded leading dimensions on some cases: the operands are column ranges of wider matrices in the model
+    lda, ldb = M + (8 if K % 2 else 0), N + (16 if M % 3 == 0 else 0)
+    a_full, b_full = torch.randn(K, lda).bfloat16(), torch.randn(K, ldb).bfloat16()
+    a, b = a_full[:, :M], b_full[:, :N]
+    c0 = torch.randn(M, N)
+    want = c0.double() + a.double().t() @ b.double()
+    cd = dev(c0)
+    hb.wgrad_bf16_(cd, dev(a_full)[:, :M], dev(b_full)[:, :N])
+    err = (cd.cpu().double() - want).abs().max().item()
+    assert err <= 2e-5 * K ** 0.5 + 1e-6, (err, K)
+    # accumulates: a second call adds the product again
+    hb.wgrad_bf16_(cd, dev(a_full)[:, :M], dev(b_full)[:, :N])
+    want2 = want + a.double().t() @ b.double()
+    assert (cd.cpu().double() - want2).abs().max().item() <= 4e-5 * K ** 0.5 + 1e-6
+
+
+def test_deferred_param_grads_match_immediate(hb):
+    """With gradient sinks (FusedAdam) the nets' parameter gradients are queued and flushed as one grouped call by the
+    optimizer: same gradients as the immediate path (FHVAE_NO_DEFER semantics via set_defer_param_grads(False))."""
+    from fhvae import FHVAE
+    from hip_optim import FusedAdam
+    from train_model import loss_function
+
+    T, F, H, D, B, S = 20, 80, 128, 16, 128, 50
+    g = torch.Generator().manual_seed(9)
+    x, idx, ns = torch.randn(B, T, F, generator=g).cuda(), torch.randint(0, S, (B,), generator=g), torch.randint(20, 200, (B,), generator=g)
+    eps = (torch.randn(B, D, generator=g).cuda(), torch.randn(B, D, generator=g).cuda())
+    grads = []
+    for defer in (True, False):
+        hb.set_defer_param_grads(defer)
+        try:
+            torch.manual_seed(4)
+            m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T, num_seqs=S, reference_compat=False, compute_dtype="bf16").cuda()
+            opt = FusedAdam(m.parameters(), lr=1e-3, betas=(0.95, 0.999))
+            opt.zero_grad()
+            out = m(x, idx, S, ns, eps=eps)
+            loss_function(out[0], out[1], 10.0).backward()
+            assert bool(hb._DEFER["pending"]) == defer
+            grads.append(opt.flat_grad().clone())
+            assert not hb._DEFER["pending"]
+        finally:
+            hb.set_defer_param_grads(True)
+    scale = grads[1].abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() <= 1e-4 * scale, ((grads[0] - grads[1]).abs().max().item(), scale)
+
+
 def test_to_time_major(hb):
     x = torch.randn(6, 5, 12)
     close(hb.to_time_major(dev(x)), x.transpose(0, 1).contiguous(), rtol=0)

@@ -26,6 +26,15 @@ def gemm(M, K, N, dtype):
     us = timeit(f)
     print("gemm %s M=%d K=%d N=%d: %.1f us  %.1f TFLOP/s" % ("bf16" if dtype else "f32", M, K, N, us, 2.0 * M * K * N / us / 1e6))
 
+def wgrad(K, M, N, n=1):
+    """C[M,N] += A[K,M]^T . B[K,N], bf16 K-major operands (csrc/wgrad.hip): the weight-gradient contraction; n problems at once
+    through fhvae_wgrad_bf16 one by one (the model's grouped launch is timed by bench.py's op timers)."""
+    a = torch.randn(K, M, device="cuda").bfloat16(); b = torch.randn(K, N, device="cuda").bfloat16()
+    c = torch.zeros(M, N, device="cuda")
+    us = timeit(lambda: hb.wgrad_bf16_(c, a, b))
+    print("wgrad bf16 K=%d M=%d N=%d: %.1f us  %.1f TFLOP/s" % (K, M, N, us, 2.0 * M * K * N / us / 1e6))
+
+
 def lstm(B, T, I, Ic, H, L, dtype, bwd=True):
     torch.manual_seed(0)
     params = []
@@ -62,6 +71,13 @@ if __name__ == "__main__":
         gemm(256, 256, 1024, dt)
         gemm(256, 512, 1024, dt)
         gemm(2048, 512, 1024, dt)
+    wgrad(4096, 4096, 4096)
+    wgrad(40960, 1024, 256)
+    wgrad(40960, 1024, 80)
+    wgrad(5120, 1024, 256)
+    wgrad(40960, 2048, 512)
+    if "--gemm-only" in sys.argv:
+        sys.exit(0)
     for dt in (hb.F32, hb.BF16):
         lstm(256, 20, 80, 0, 256, 2, dt)
         lstm(256, 20, 80, 32, 256, 2, dt)
