@@ -42,29 +42,12 @@ __device__ __forceinline__ int yoff(int row, int ch) {  // byte offset of 16-byt
   return row * (D * 4) + ((ch ^ (row & (CHN >= 8 ? 7 : CHN - 1))) << 4);
 }
 
-// The (query, own table row) pair in the DIRECT form -c |x - y|^2 (x from global memory, y from the LDS tile).  The expanded
-// form's absolute error ~1e-7 * 2c (|q|^2 + |t|^2) is harmless on far rows (their softmax weight is 0 either way) but it is
-// the whole signal on the pair training drives together (q -> table[idx]): that one logit per query is taken exactly, in the
-// forward's log-sum-exp and in both backward passes, so CE -> log(1 + sum_others) and p_target - 1 -> -sum_others cleanly.
-template <int D>
-__device__ __forceinline__ float direct_logit(const float* __restrict__ xrow, const char* ytile, int yrow, float c) {
-  // summation order of loss.hip's sqdist<D> (even / odd accumulators), which the forward's target logit uses: a target row
-  // that is the row maximum then gives (max - target) == 0 bit for bit
-  float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-  for (int ch = 0; ch < D / 4; ++ch) {
-    const uint4 u = *(const uint4*)(ytile + yoff<D>(yrow, ch));
-    const float4 xv = *(const float4*)(xrow + 4 * ch);
-    const float d0 = xv.x - __uint_as_float(u.x), d1 = xv.y - __uint_as_float(u.y), d2 = xv.z - __uint_as_float(u.z),
-                d3 = xv.w - __uint_as_float(u.w);
-    a0 = fmaf(d0, d0, a0);
-    a1 = fmaf(d1, d1, a1);
-    a0 = fmaf(d2, d2, a0);
-    a1 = fmaf(d3, d3, a1);
-  }
-  return -c * (a0 + a1);
-}
-
+// The (query, own table row) pairs are NOT computed here.  The expanded form's absolute error ~1e-7 * 2c (|q|^2 + |t|^2) is
+// harmless on far rows (their softmax weight is 0 either way) but it is the whole signal on the pair training drives together
+// (q -> table[idx]).  That one logit per query is therefore masked out of these kernels (logit = -inf: no contribution to the
+// log-sum-exp, zero weight in both backward passes) and taken in the DIRECT form -c |q - t|^2 by the callers: the forward's
+// combine kernel merges exp(target - max) into the row sum, the backward adds the pair's gradient in disc_own_bwd_kernel
+// (loss.hip).  CE -> log(1 + sum_others) and p_target - 1 -> -sum_others then come out cleanly however large the norms are.
 template <int D, int MODE>
 __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
   constexpr int CHN = D / 4;   // 16-byte chunks per vector
@@ -220,13 +203,9 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int y = y0 + yb * 16 + 4 * g + r;
           lg[r] = (xok && y < y_end) ? 2.f * a.c * acc[r] - a.c * (ynr[r] + xn[t]) : -INFINITY;
-          // the query's own row: exact (rare: one pair per query and pass)
-          bool own;
-          if (MODE == 1 && !a.x_is_query)
-            own = ytg[r] == xtgt[t];
-          else
-            own = xtgt[t] == y;
-          if (own && xok && y < y_end) lg[r] = direct_logit<D>(a.X + (int64_t)(x0 + t * 16 + i) * D, ytile, yb * 16 + 4 * g + r, a.c);
+          // the query's own row is handled exactly by the callers (see the note above the kernel)
+          const bool own = (MODE == 1 && !a.x_is_query) ? ytg[r] == xtgt[t] : xtgt[t] == y;
+          if (own) lg[r] = -INFINITY;
         }
         if constexpr (MODE == 0) {
           const float gm = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
@@ -242,16 +221,12 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
           float w[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int yl = y0 + yb * 16 + 4 * g + r;  // global streamed index
-            float p, hit;
-            if (a.x_is_query) {
+            float p;
+            if (a.x_is_query)
               p = __expf(lg[r] - xmax[t]) * xinv[t];
-              hit = (xtgt[t] == yl) ? 1.f : 0.f;
-            } else {
+            else
               p = __expf(lg[r] - ymx[r]) * yiv[r];
-              hit = (ytg[r] == xtgt[t]) ? 1.f : 0.f;
-            }
-            w[r] = (lg[r] > -INFINITY) ? gscale * (p - hit) : 0.f;
+            w[r] = (lg[r] > -INFINITY) ? gscale * p : 0.f;  // (own pairs: masked above, added by disc_own_bwd_kernel)
             wsum[t] += w[r];
           }
           // G^T[d][x] += sum_y Y[y][d] * w[y][x]: A = Y^T from LDS (lane: d = 16*dj + i, y = 4g + r), B = w[r]

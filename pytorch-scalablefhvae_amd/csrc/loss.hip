@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void disc_combine_kernel(const float* __restri
                                                            const int64_t* __restrict__ idx, int64_t row0, float c,
                                                            const float2* __restrict__ part, int nchunks,
                                                            float* __restrict__ row_max, float* __restrict__ row_sum,
-                                                           float* __restrict__ tgt, int B, int S) {
+                                                           float* __restrict__ tgt, int B, int S, int own_excluded) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -311,10 +311,47 @@ __global__ __launch_bounds__(256) void disc_combine_kernel(const float* __restri
 #pragma unroll
       for (int d = 0; d < D; ++d) qr[d] = q[(int64_t)b * D + d];
       t = -c * sqdist<D>(qr, table + s * D);
+      if (own_excluded) {
+        // the MFMA kernels left the query's own row out of the partials (disc_mfma.hip): its exact logit joins here
+        const float nm = fmaxf(gm, t);
+        sum = (gm == -INFINITY ? 0.f : sum * __expf(gm - nm)) + __expf(t - nm);
+        row_max[b] = nm;
+        row_sum[b] = sum;
+        tgt[b] = t;
+        return;
+      }
     }
     row_max[b] = gm;
     row_sum[b] = sum;
     tgt[b] = t;
+  }
+}
+
+// Backward of the (query, own row) pairs the MFMA kernels leave out: w = g (p_own - 1), p_own = exp(target - max) / sum with the
+// DIRECT-form target logit; dq[b] += -2c w (q_b - t_y), dtable[y] += +2c w (q_b - t_y).  One thread per (query, 4 dims).
+template <int D>
+__global__ __launch_bounds__(256) void disc_own_bwd_kernel(const float* __restrict__ q, const float* __restrict__ table,
+                                                           const int64_t* __restrict__ idx, int64_t row0, float c,
+                                                           const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                           const float* __restrict__ gsc, float gmul, float* __restrict__ dq,
+                                                           float* __restrict__ dtable, int B, int S) {
+  constexpr int PER = D / 4;  // threads per query
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int b = tid / PER, part = tid % PER;
+  if (b >= B) return;
+  const int64_t s = idx[b] - row0;
+  if (s < 0 || s >= S) return;
+  float qr[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) qr[d] = q[(int64_t)b * D + d];
+  const float t = -c * sqdist<D>(qr, table + s * D);
+  const float w = (*gsc) * gmul * (__expf(t - rmax[b]) / rsum[b] - 1.f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = part * 4 + k;
+    const float diff = qr[d] - table[s * D + d];
+    if (dq) atomicAdd(dq + (int64_t)b * D + d, -2.f * c * w * diff);
+    if (dtable) atomicAdd(dtable + s * D + d, 2.f * c * w * diff);
   }
 }
 
@@ -673,9 +710,10 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
   hipStream_t st = (hipStream_t)stream;
   DiscPlan p = disc_plan(B, S);
   float2* part = (float2*)ws;
-  int e;
+  int e, own_excluded = 0;
   if (disc_mfma_supported(B, S, D) && !getenv("FHVAE_DISC_VALU")) {
     e = disc_mfma_fwd(q, table, idx, row0, inv_two_var, part, &p.nchunks, B, S, D, st);
+    own_excluded = 1;
   } else {
     dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
     DISC_DISPATCH(D, hipLaunchKernelGGL((disc_fwd_kernel<DD>), grid, dim3(256), 0, st, q, table, inv_two_var, part, (int)B,
@@ -684,7 +722,8 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
   }
   if (e) return e;
   DISC_DISPATCH(D, hipLaunchKernelGGL((disc_combine_kernel<DD>), dim3((unsigned)fh_cdiv(B, 4)), dim3(256), 0, st, q, table, idx,
-                                      row0, inv_two_var, part, p.nchunks, row_max, row_sumexp, tgt_logit, (int)B, (int)S));
+                                      row0, inv_two_var, part, p.nchunks, row_max, row_sumexp, tgt_logit, (int)B, (int)S,
+                                      own_excluded));
   e = fh_launch_status();
   if (e) return e;
   if (ce_mean) {
@@ -739,7 +778,15 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
       hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
       if (he != hipSuccess) return (int)he;
     }
-    return disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, B, S, D, st);
+    int e = disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, B, S, D, st);
+    if (e) return e;
+    if (dq || dtable) {
+      DISC_DISPATCH(D, hipLaunchKernelGGL((disc_own_bwd_kernel<DD>), dim3((unsigned)fh_cdiv(B * (DD / 4), 256)), dim3(256), 0, st, q,
+                                          table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, (int)B,
+                                          (int)S));
+      e = fh_launch_status();
+    }
+    return e;
   }
   if (dq) {
     hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);

@@ -361,7 +361,9 @@ class _Linear(torch.autograd.Function):
         dx, dw, db = raw_linear_bwd(x, w, y, dy, ctx.relu, need_dx=ctx.needs_input_grad[0],
                                     need_dw=ctx.needs_input_grad[1], need_db=ctx.needs_input_grad[2],
                                     dw_sink=ctx.sinks[0], db_sink=ctx.sinks[1])
-        return dx, dw, db, None
+        # a gradient that went straight into the optimizer's sink must NOT be handed to autograd as well (AccumulateGrad
+        # would add the sink to itself: the FC model's weight gradients were doubled under FusedAdam)
+        return dx, (None if ctx.sinks[0] is not None else dw), (None if ctx.sinks[1] is not None else db), None
 
 
 def linear(x, w, b, relu=False):
