@@ -395,6 +395,10 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
+    if os.environ.get("FHVAE_BENCH_WATCHDOG"):  # diagnostics: dump every thread's Python stack and exit if the run takes longer
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["FHVAE_BENCH_WATCHDOG"]), exit=True)
 
     import torch
 

@@ -21,6 +21,7 @@
 #include "wgrad.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "gemm_core.h"
 
@@ -79,7 +80,11 @@ __device__ __forceinline__ bf16x8 wg_frag(const char* img, int off, int j) {
   return u.v;
 }
 
-template <int BN>
+// VAR (tuning / ablation builds; 0 ships... see launch_class): 0 = all DMA pieces of the next stage at the top of a step,
+// counted wait; 1 = the pieces issued in two halves behind each 32-k block's fragment reads (their issue cost then overlaps the
+// LDS latency), plain vmcnt(0) at the top of the next step (they have had a whole step to land); 2 = ablation, no DMA in the
+// loop; 3 = ablation, DMA only (no fragment reads, no MFMAs)
+template <int BN, int VAR>
 __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
   using IA = WgImg<kWgBM>;
   using IB = WgImg<BN>;
@@ -149,8 +154,9 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
     wg_issue<kWgBM>(st, rsa, va, in ? (unsigned)(ks * kWgBK) * lda_b : kOob, wave);
     wg_issue<BN>(st + IA::BYTES, rsb, vb, in ? (unsigned)(ks * kWgBK) * ldb_b : kOob, wave);
   };
-  auto compute = [&](const char* As) {
+  auto compute = [&](const char* As, char* nxt, int ks_next) {
     const char* Bs = As + IA::BYTES;
+    if constexpr (VAR == 3) return;
 #pragma unroll
     for (int j = 0; j < kWgBK / 32; ++j) {
       bf16x8 a[TM], b[TN];
@@ -158,6 +164,13 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
       for (int tn = 0; tn < TN; ++tn) b[tn] = wg_frag<IB::RB>(Bs, offb[tn], j);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) a[tm] = wg_frag<IA::RB>(As, offa[tm], j);
+      if constexpr (VAR == 1) {  // this half of the next stage's DMA pieces: issued while the fragment reads are in flight
+        const bool in = ks_next < ks1;
+        if (j == 0)
+          wg_issue<kWgBM>(nxt, rsa, va, in ? (unsigned)(ks_next * kWgBK) * lda_b : kOob, wave);
+        else
+          wg_issue<BN>(nxt + IA::BYTES, rsb, vb, in ? (unsigned)(ks_next * kWgBK) * ldb_b : kOob, wave);
+      }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
@@ -172,10 +185,14 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
   // two steps (one per LDS object): an odd slice gets one padding step whose operands are the zeros of out-of-range loads,
   // and the look-ahead DMA of the last step is such a zero fill too.
   auto step = [&](const char* cur, char* nxt, int ks_next) {
-    issue(nxt, ks_next);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+    if constexpr (VAR == 0 || VAR == 3) {
+      issue(nxt, ks_next);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // every wave's pieces of the current stage have landed
-    compute(cur);
+    compute(cur, nxt, ks_next);
     __builtin_amdgcn_s_barrier();  // every wave is done reading it: the next step may refill it
   };
   issue(stage0, ks0);
@@ -199,8 +216,12 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
     }
 }
 
-template __global__ void wgrad_kernel<256>(WgGroup);
-template __global__ void wgrad_kernel<128>(WgGroup);
+template __global__ void wgrad_kernel<256, 0>(WgGroup);
+template __global__ void wgrad_kernel<256, 1>(WgGroup);
+template __global__ void wgrad_kernel<256, 2>(WgGroup);
+template __global__ void wgrad_kernel<256, 3>(WgGroup);
+template __global__ void wgrad_kernel<128, 0>(WgGroup);
+template __global__ void wgrad_kernel<128, 1>(WgGroup);
 
 bool wgrad_eligible(const WgProblem& p) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.B || !p.C) return false;
@@ -249,7 +270,16 @@ static int launch_class(const WgProblem* ps, const int* which, int n, hipStream_
       g.p[k] = p;
       g.base[k + 1] = g.base[k] + p.m_tiles * p.n_tiles * p.splitk;
     }
-    hipLaunchKernelGGL((wgrad_kernel<BN>), dim3((unsigned)g.base[cnt]), dim3(kWgThreads), 0, st, g);
+    static const int var = getenv("FHVAE_WGRAD_VAR") ? atoi(getenv("FHVAE_WGRAD_VAR")) : 0;
+    const dim3 grid((unsigned)g.base[cnt]), block(kWgThreads);
+    if (var == 1)
+      hipLaunchKernelGGL((wgrad_kernel<BN, 1>), grid, block, 0, st, g);
+    else if (BN == 256 && var == 2)
+      hipLaunchKernelGGL((wgrad_kernel<256, 2>), grid, block, 0, st, g);
+    else if (BN == 256 && var == 3)
+      hipLaunchKernelGGL((wgrad_kernel<256, 3>), grid, block, 0, st, g);
+    else
+      hipLaunchKernelGGL((wgrad_kernel<BN, 0>), grid, block, 0, st, g);
     const int e = fh_launch_status();
     if (e) return e;
   }
