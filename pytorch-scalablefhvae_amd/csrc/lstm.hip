@@ -659,14 +659,18 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
   // (at small batches each is a latency-bound launch of a few workgroups)
   GemmParams grp[2 * FHVAE_MAX_LAYERS];
   int ng = 0;
+  // the persistent backward may have left dgates in the blocked layout (cluster_dg_blocked): only wgrad.hip reads that
+  const bool dg_blocked = sizeof(T) == 2 && wq && cluster_dg_blocked(bd);
+  bool blocked_unread = false;
   // -> true: taken by the dedicated long-K kernel (queued in wq)
   auto wgrad_long = [&](const void* a, int64_t lda, const void* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc, int64_t Ncols) {
-    if (!wq || sizeof(T) != 2 || Kc < kWgradMinK) return false;
+    if (!wq || sizeof(T) != 2 || (!dg_blocked && Kc < kWgradMinK)) return false;
     WgProblem w = {};
     w.A = (const u16*)a, w.B = (const u16*)b, w.C = c;
     w.lda = lda, w.ldb = ldb, w.ldc = ldc;
     w.M = (int)G, w.N = (int)Ncols, w.K = (int)Kc;
-    if (!wgrad_eligible(w)) return false;
+    w.a_blk_rows = dg_blocked ? (int)B : 0;
+    if (!wgrad_eligible(w)) return dg_blocked ? (blocked_unread = true, false) : false;
     wq->push_back(w);
     return true;
   };
@@ -712,6 +716,7 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
       if (e) return e;
     }
   }
+  if (blocked_unread) return FHVAE_ERR_ALIGN;  // (cannot happen: cluster_dg_blocked implies wgrad's preconditions)
   return flush();
 }
 

@@ -36,6 +36,8 @@ bool cluster_can_fold(const fhvae_lstm_desc* d);
 bool cluster_xc_in_kernel(const fhvae_lstm_desc* d);
 // the recurrence of fhvae_lstm_seq_fwd after the layer-0 input projection (d->pre filled): all T steps, all layers
 int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st);
+// bd->dgates is (to be) written in the blocked layout [l][t][4H/32][B][32] instead of row-major (L,T,B,4H)
+bool cluster_dg_blocked(const fhvae_lstm_bwd_desc* bd);
 // the recurrence of fhvae_lstm_seq_bwd: fills dgates (and dgsum when Ic > 0)
 int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st);
 

@@ -1610,7 +1610,12 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
 // weights.  It is a K-split partial sum over the same unit tiles as the recurrent product, so it simply starts the accumulators
 // -- and it does not depend on the exchange, so its 64 MFMAs per wave run while the exchange loads are in flight.  The
 // (T*B x 4H x H) GEMM between the two launches of a net and its f32 (T,B,H) round trip are gone.
-template <int H, int RT, bool ABOVE>
+// BLK: the gate gradients are kept ONLY in the blocked form [t][k-step][batch row][32] (the layout of the exchange buffer, with
+// one slot per time step instead of two parities, in the dgates buffer itself): the step's exchange store IS the saved dg, the
+// row-major copy (84 MB written per launch at B = 2048, its LDS image and, with ABOVE, the barrier that protected that image)
+// is gone, the from-above operand of the layer below is read as 1-KB fragments instead of 16 x 64 B at the row stride, and the
+// weight-gradient kernel (wgrad.hip, WgProblem::a_blk_rows) takes its A operand from the blocked layout.
+template <int H, int RT, bool ABOVE, bool BLK>
 __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
   constexpr int HU = 64, UT = 4;
   constexpr int G = 4 * H, GC = G / 8, KB = GC / 64, KS = G / 32, KPW = KS / 4;
@@ -1673,7 +1678,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
   auto pack4 = [](const f32x4& v) -> uint2 {
     return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
   };
-  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(p.xch);
+  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(BLK ? (const void*)p.dg : (const void*)p.xch);
   unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
   __syncthreads();  // weights have landed (and every thread has read the join word)
 
@@ -1702,9 +1707,15 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
       const int tc = t > 0 ? t : 0;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const u16* src = p.dg_above + ((int64_t)tc * B + rowc[rt]) * G + (((kp * KPW) << 2) | q) * 8;
+        if constexpr (BLK) {  // blocked dg of the layer above: k-step ks of row r at ((t * KS + ks) * B + r) * 32
+          const u16* src = p.dg_above + (((int64_t)tc * KS + kp * KPW) * B + rowc[rt]) * 32 + q * 8;
 #pragma unroll
-        for (int j = 0; j < KPW; ++j) a2n[rt][j] = *(const uint4*)(src + j * 32);
+          for (int j = 0; j < KPW; ++j) a2n[rt][j] = *(const uint4*)(src + (int64_t)j * B * 32);
+        } else {
+          const u16* src = p.dg_above + ((int64_t)tc * B + rowc[rt]) * G + (((kp * KPW) << 2) | q) * 8;
+#pragma unroll
+          for (int j = 0; j < KPW; ++j) a2n[rt][j] = *(const uint4*)(src + j * 32);
+        }
       }
     }
   };
@@ -1764,7 +1775,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
       uint4 a[RT][KPW];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const int64_t base = (xch_off((s - 1) & 1, 0, 1, KS, kp * KPW, B, rowc[rt]) + q * 8) * 2;
+        // BLK: the slot of time t + 1 (written by the members in the previous step); else the previous step's parity
+        const int64_t base = (xch_off(BLK ? t + 1 : (s - 1) & 1, 0, 1, KS, kp * KPW, B, rowc[rt]) + q * 8) * 2;
 #pragma unroll
         for (int j = 0; j < KPW; ++j) a[rt][j] = load_sc1(dg_rs, base + j * (B * 64));
       }
@@ -1785,7 +1797,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
       __builtin_amdgcn_sched_barrier(0);
       load_above(t - 1);  // behind the exchange loads and their MFMAs: lands during the epilogue
     }
-    if constexpr (ABOVE) __syncthreads();  // every wave has read the dg image of the previous step out of the partial tiles
+    if constexpr (ABOVE && !BLK) __syncthreads();  // every wave has read the dg image of the previous step out of the partial tiles
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -1819,11 +1831,15 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
         for (int g = 0; g < 4; ++g) {
           dgs[rt][g] += dp[g];
           dpk[rt][g] = pack4(dp[g]);
-          *(uint2*)(p.xch + xch_off(s & 1, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];  // what the members wait for
-          if constexpr (ABOVE)
-            *(uint2*)stg_alias(wave, rt, r, g, q * 8) = dpk[rt][g];
-          else
-            *(uint2*)(Stg + (rt * 16 + r) * kStgRow + g * (HU * 2) + (wave * 16 + q * 4) * 2) = dpk[rt][g];
+          if constexpr (BLK) {  // slot t of the blocked dg: what the members wait for AND what is saved
+            *(uint2*)(p.dg + xch_off(t, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];
+          } else {
+            *(uint2*)(p.xch + xch_off(s & 1, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];  // what the members wait for
+            if constexpr (ABOVE)
+              *(uint2*)stg_alias(wave, rt, r, g, q * 8) = dpk[rt][g];
+            else
+              *(uint2*)(Stg + (rt * 16 + r) * kStgRow + g * (HU * 2) + (wave * 16 + q * 4) * 2) = dpk[rt][g];
+          }
         }
       }
     }
@@ -1833,7 +1849,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
     CL_TLOG(s * 8 + 4);
     // the row-major copy the weight-gradient contractions read leaves through the LDS image as whole 128-byte lines (a lane's
     // own values are 8-byte pieces of 16 different lines per instruction)
-    {
+    if constexpr (!BLK) {
       uint4 v[RT * 2];
 #pragma unroll
       for (int i = 0; i < RT * 2; ++i) {
@@ -2078,21 +2094,36 @@ static int launch_bwd_layer_rb(const ClBwd& p, int RB, hipStream_t st) {
   }
 }
 
-template <int RT, bool ABOVE>
+template <int RT, bool ABOVE, bool BLK>
 static int launch_bwd_layer_ks_a(const ClBwd& p, hipStream_t st) {
   constexpr int SMEM = ABOVE ? 64 * (4 * 256 / 8) * 16 + 4 * RT * 4 * 1024 : 4 * RT * 4 * 1024 + RT * 16 * (4 * 64 * 2 + 16);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_ks_kernel<256, RT, ABOVE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_ks_kernel<256, RT, ABOVE, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL((lstm_bwd_layer_ks_kernel<256, RT, ABOVE>), dim3(kGrid), dim3(kThreads), SMEM, st, p);
+  hipLaunchKernelGGL((lstm_bwd_layer_ks_kernel<256, RT, ABOVE, BLK>), dim3(kGrid), dim3(kThreads), SMEM, st, p);
   return fh_launch_status();
 }
 template <int RT>
-static int launch_bwd_layer_ks(const ClBwd& p, hipStream_t st) {
-  return p.dg_above ? launch_bwd_layer_ks_a<RT, true>(p, st) : launch_bwd_layer_ks_a<RT, false>(p, st);
+static int launch_bwd_layer_ks(const ClBwd& p, bool blk, hipStream_t st) {
+  if (blk) return p.dg_above ? launch_bwd_layer_ks_a<RT, true, true>(p, st) : launch_bwd_layer_ks_a<RT, false, true>(p, st);
+  return p.dg_above ? launch_bwd_layer_ks_a<RT, true, false>(p, st) : launch_bwd_layer_ks_a<RT, false, false>(p, st);
+}
+
+// Whether the backward of this net keeps its gate gradients only in the blocked layout (lstm_bwd_layer_ks_kernel<.., BLK>): the
+// per-layer contraction-split kernels with the fused from-above term run (H = 256, rows form), every time slot is a whole number
+// of 64-row wgrad k-steps, and the weight gradients go through wgrad.hip (which reads that layout).  Both phases of
+// fhvae_lstm_seq_bwd evaluate this: the layout of bd->dgates follows from the descriptor alone.
+bool cluster_dg_blocked(const fhvae_lstm_bwd_desc* bd) {
+  const fhvae_lstm_desc* d = &bd->f;
+  if (!cluster_eligible(d) || cluster_form(d) != 1 || d->H != 256) return false;
+  if (!(d->L == 1 || bd->ws_below) || getenv("FHVAE_NO_LAYERWISE") || getenv("FHVAE_NO_LAYER_KS") || getenv("FHVAE_NO_FUSE_ABOVE")) return false;
+  if (getenv("FHVAE_NO_WGRAD") || getenv("FHVAE_NO_DG_BLOCKED")) return false;
+  if (d->B % 64 != 0 || d->T < 2 || d->I % 8 != 0) return false;
+  if ((int64_t)d->T * d->B * 4 * d->H * 2 >= (1LL << 30)) return false;  // wgrad's 32-bit buffer offsets
+  return true;
 }
 
 // rows form, layer by layer (see lstm_bwd_layer_kernel): top layer first, then the from-above contraction as one GEMM into
@@ -2107,6 +2138,7 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
   const bool ks = H == 256 && !getenv("FHVAE_NO_LAYER_KS");
   // contraction-split form: a layer below the top computes the from-above term itself (no GEMM, no ws_below round trip)
   const bool fuse_above = ks && !getenv("FHVAE_NO_FUSE_ABOVE");
+  const bool blk = cluster_dg_blocked(bd);  // (implies ks and fuse_above)
   const int HU = ks ? 64 : 32;
   const int NU = H / HU, NC = kGrid / NU;
   const int64_t B = d->B, T = d->T, G = 4 * H;
@@ -2140,7 +2172,7 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
       const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * ((T - 1) + (p.dg_above ? T : 0)) * 4.0 * H);
       p.xch = w.xch;
-      const int e = ks ? (RB <= 16 ? launch_bwd_layer_ks<1>(p, st) : launch_bwd_layer_ks<2>(p, st))
+      const int e = ks ? (RB <= 16 ? launch_bwd_layer_ks<1>(p, blk, st) : launch_bwd_layer_ks<2>(p, blk, st))
                        : (H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st));
       trace_end(st, ts);
       if (e) return e;

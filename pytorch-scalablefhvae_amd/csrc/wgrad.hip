@@ -54,6 +54,18 @@ __device__ __forceinline__ void wg_dma_offsets(unsigned (&voff)[WgImg<W>::NI], u
   }
 }
 
+// the same for an A operand in the blocked layout (WgProblem::a_blk_rows = R): 32-column blocks of R rows x 64 B per time slot
+__device__ __forceinline__ void wg_dma_offsets_blk(unsigned (&voff)[WgImg<kWgBM>::NI], unsigned R, int wave, int lane) {
+  using I = WgImg<kWgBM>;
+#pragma unroll
+  for (int q = 0; q < I::NI; ++q) {
+    const int row = (wave * I::NI + q) * I::RPI + lane / I::CPR;
+    const int pc = lane % I::CPR;
+    const int c = ((((pc >> 1) ^ (row & 7)) << 1) | (pc & 1));
+    voff[q] = ((unsigned)(c >> 2) * R + (unsigned)row) * 64u + (unsigned)(c & 3) * 16u;
+  }
+}
+
 template <int W>
 __device__ __forceinline__ void wg_issue(char* stage, __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[WgImg<W>::NI], unsigned kbase,
                                          int wave) {
@@ -80,10 +92,12 @@ __device__ __forceinline__ bf16x8 wg_frag(const char* img, int off, int j) {
   return u.v;
 }
 
-// VAR (tuning / ablation builds; 0 ships... see launch_class): 0 = all DMA pieces of the next stage at the top of a step,
-// counted wait; 1 = the pieces issued in two halves behind each 32-k block's fragment reads (their issue cost then overlaps the
-// LDS latency), plain vmcnt(0) at the top of the next step (they have had a whole step to land); 2 = ablation, no DMA in the
-// loop; 3 = ablation, DMA only (no fragment reads, no MFMAs)
+// VAR (FHVAE_WGRAD_VAR; 1 ships): 0 = all DMA pieces of the next stage at the top of a step, counted wait; 1 = the pieces issued
+// in two halves behind each 32-k block's fragment reads (their issue cost then overlaps the LDS latency), plain vmcnt(0) at the
+// top of the next step (they have had a whole step to land); 2 = ablation, no DMA in the loop; 3 = ablation, DMA only (no
+// fragment reads, no MFMAs).  Measured at 4096^3 (64 steps per workgroup + 67 MB of epilogue): 0: 173 us, 1: 159-164 us,
+// 2: 141 us, 3: 98 us -- the fragment-read + MFMA phases between the two barriers of a step bound the loop (~970 TFLOP/s with
+// no DMA at all); a software pipeline over the (32-k block, m-tile) groups pinned with sched_group_barrier was no faster (173 us).
 template <int BN, int VAR>
 __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
   using IA = WgImg<kWgBM>;
@@ -125,13 +139,24 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
   // buffer descriptors from the tile's first column: offsets past the last valid k-row read as zero (K tail); columns past
   // M / N inside a row read the neighbouring bytes (in bounds) and only feed output columns that are never stored
   const unsigned lda_b = (unsigned)p.lda * 2u, ldb_b = (unsigned)p.ldb * 2u;
-  const __amdgpu_buffer_rsrc_t rsa =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.A + m0), 0, (int)(((int64_t)p.K * p.lda - m0) * 2), 0x00020000);
+  const unsigned blkR = (unsigned)p.a_blk_rows;  // > 0: blocked A (the tile's column offset then goes into the step offset)
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(p.A + (blkR ? 0 : m0)), 0, (int)(((int64_t)p.K * p.lda - (blkR ? 0 : m0)) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsb =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.B + n0), 0, (int)(((int64_t)p.K * p.ldb - n0) * 2), 0x00020000);
   unsigned va[IA::NI], vb[IB::NI];
-  wg_dma_offsets<kWgBM>(va, lda_b, wave, lane);
+  if (blkR)
+    wg_dma_offsets_blk(va, blkR, wave, lane);
+  else
+    wg_dma_offsets<kWgBM>(va, lda_b, wave, lane);
   wg_dma_offsets<BN>(vb, ldb_b, wave, lane);
+  // byte offset of k-step ks of the A operand (uniform): row-major ks * 64 rows; blocked: slot t = k0 / R, rows b0 = k0 % R of
+  // the tile's first 32-column block
+  auto a_step = [&](int ks) -> unsigned {
+    if (!blkR) return (unsigned)(ks * kWgBK) * lda_b;
+    const unsigned k0 = (unsigned)(ks * kWgBK), t = k0 / blkR, b0 = k0 - t * blkR;
+    return ((t * (unsigned)(p.lda >> 5) + (unsigned)(m0 >> 5)) * blkR + b0) * 64u;
+  };
 
   // fragment read offsets: k-row 4g + (i >> 2) of the 32-k block, 32-byte segment (col0 / 16) ^ (k & 7), 8 bytes per lane
   const int kr = 4 * gq + (i >> 2), x = kr & 7;
@@ -151,7 +176,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
   constexpr unsigned kOob = 0x40000000u;  // >= num_records (wgrad_eligible: operands < 2^30 bytes)
   auto issue = [&](char* st, int ks) {
     const bool in = ks < ks1;
-    wg_issue<kWgBM>(st, rsa, va, in ? (unsigned)(ks * kWgBK) * lda_b : kOob, wave);
+    wg_issue<kWgBM>(st, rsa, va, in ? a_step(ks) : kOob, wave);
     wg_issue<BN>(st + IA::BYTES, rsb, vb, in ? (unsigned)(ks * kWgBK) * ldb_b : kOob, wave);
   };
   auto compute = [&](const char* As, char* nxt, int ks_next) {
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
       if constexpr (VAR == 1) {  // this half of the next stage's DMA pieces: issued while the fragment reads are in flight
         const bool in = ks_next < ks1;
         if (j == 0)
-          wg_issue<kWgBM>(nxt, rsa, va, in ? (unsigned)(ks_next * kWgBK) * lda_b : kOob, wave);
+          wg_issue<kWgBM>(nxt, rsa, va, in ? a_step(ks_next) : kOob, wave);
         else
           wg_issue<BN>(nxt + IA::BYTES, rsb, vb, in ? (unsigned)(ks_next * kWgBK) * ldb_b : kOob, wave);
       }
@@ -211,7 +236,13 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 128 + tm * 16 + 4 * gq + r;
-        if (m < p.M && n < p.N) atomicAdd(p.C + (int64_t)m * p.ldc + n, acc[tm][tn][r]);
+        if (m < p.M && n < p.N) {
+          float* c = p.C + (int64_t)m * p.ldc + n;
+          if (p.splitk == 1)
+            *c += acc[tm][tn][r];  // the only workgroup on this tile: plain read-modify-write (the atomic path adds ~1.3 TB/s)
+          else
+            atomicAdd(c, acc[tm][tn][r]);
+        }
       }
     }
 }
@@ -229,6 +260,7 @@ bool wgrad_eligible(const WgProblem& p) {
   if ((p.lda % 8) || (p.ldb % 8) || p.lda < p.M || p.ldb < p.N) return false;
   // 32-bit buffer offsets / num_records
   if ((int64_t)p.K * p.lda * 2 >= (1LL << 30) || (int64_t)p.K * p.ldb * 2 >= (1LL << 30)) return false;
+  if (p.a_blk_rows < 0 || (p.a_blk_rows > 0 && ((p.a_blk_rows % 64) || (p.lda % 32) || (p.K % p.a_blk_rows)))) return false;
   return true;
 }
 
@@ -270,16 +302,16 @@ static int launch_class(const WgProblem* ps, const int* which, int n, hipStream_
       g.p[k] = p;
       g.base[k + 1] = g.base[k] + p.m_tiles * p.n_tiles * p.splitk;
     }
-    static const int var = getenv("FHVAE_WGRAD_VAR") ? atoi(getenv("FHVAE_WGRAD_VAR")) : 0;
+    static const int var = getenv("FHVAE_WGRAD_VAR") ? atoi(getenv("FHVAE_WGRAD_VAR")) : 1;
     const dim3 grid((unsigned)g.base[cnt]), block(kWgThreads);
-    if (var == 1)
-      hipLaunchKernelGGL((wgrad_kernel<BN, 1>), grid, block, 0, st, g);
+    if (var == 0)
+      hipLaunchKernelGGL((wgrad_kernel<BN, 0>), grid, block, 0, st, g);
     else if (BN == 256 && var == 2)
       hipLaunchKernelGGL((wgrad_kernel<256, 2>), grid, block, 0, st, g);
     else if (BN == 256 && var == 3)
       hipLaunchKernelGGL((wgrad_kernel<256, 3>), grid, block, 0, st, g);
     else
-      hipLaunchKernelGGL((wgrad_kernel<BN, 0>), grid, block, 0, st, g);
+      hipLaunchKernelGGL((wgrad_kernel<BN, 1>), grid, block, 0, st, g);
     const int e = fh_launch_status();
     if (e) return e;
   }
