@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 3
+#define FHVAE_ABI_VERSION 4
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -249,11 +249,15 @@ int fhvae_elbo_bwd(const fhvae_elbo_bwd_desc* d, void* stream);
  *   (0 if that row is not in [row0, row0+S)), and, if ce_mean != NULL, the single-shard scalar
  *   ce_mean = mean_b( (row_max - tgt_logit) + log(row_sumexp) )  (= the reference's log_qy).
  * ws: workspace of fhvae_disc_lse_ws_bytes(B,S) bytes.
+ * dtype (fwd and bwd; q, table and every output stay f32): FHVAE_F32 = the logits in exact f32 (direct form on the VALU, or
+ * the expanded form on exact-f32 MFMA for D = 32 and B*S >= 65536) -- the parity mode; FHVAE_BF16 (D = 32 large problems
+ * only, otherwise as F32) = the bf16 compute mode: cross terms on bf16 MFMA with hi/lo-split operands (~2^-16 relative on
+ * q.t).  In both MFMA forms the query's own row (idx) is taken in the direct f32 form.
  * ------------------------------------------------------------------------------------------ */
 int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S);
 int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
                        float inv_two_var, float* row_max, float* row_sumexp, float* tgt_logit,
-                       float* ce_mean, void* ws, int64_t B, int64_t S, int64_t D, void* stream);
+                       float* ce_mean, void* ws, int64_t B, int64_t S, int64_t D, int dtype, void* stream);
 /* Cross-shard combine helpers (multi-GPU): after an all-reduce(MAX) of row_max over the
  * shards, rescale a shard's sum to the global max:  out[b] = rsum_local[b] * exp(rmax_local[b] - m_global[b]);
  * after the all-reduce(SUM) of (out, tgt): ce = mean_b((m - tgt) + log s), single workgroup, deterministic. */
@@ -272,7 +276,7 @@ int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp, const floa
 int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
                        float inv_two_var, const float* row_max, const float* row_sumexp,
                        const float* g_scale, float g_mul, float* dq, float* dtable, void* ws,
-                       int64_t B, int64_t S, int64_t D, void* stream);
+                       int64_t B, int64_t S, int64_t D, int dtype, void* stream);
 
 /* The discriminative segment variational lower bound, train_model.py:243-251:
  *   loss = -mean_b(lower_bound[b] + alpha * log_qy) = -(mean(lower_bound) + alpha * log_qy)   (log_qy one f32 on the device)

@@ -15,26 +15,10 @@
 // with w = g (softmax - onehot) recomputed from the per-query (max, sumexp) of the forward.  The logit tile comes out
 // of the MFMA with the stationary index on the lanes (col = lane&15) and the streamed index in the 4 accumulator
 // registers (row = 4*(lane>>4)+r): exactly the B-operand layout of the second product, so w never leaves registers.
-#include "common.h"
+#include "disc_mfma.h"
 
 namespace fh {
 
-struct DiscMfmaArgs {
-  const float* X;  // stationary [NX, D]
-  const float* Y;  // streamed   [NY, D]
-  int NX, NY;
-  float c;
-  int x_is_query;
-  const int64_t* idx;  // per QUERY target row (global); query b hits local row idx[b] - row0
-  int64_t row0;
-  const float* rmax;   // per query (MODE 1)
-  const float* rsum;
-  const float* gsc;    // device scalar
-  float gmul;
-  float2* part;        // MODE 0: [nchunks][NX]
-  float* G;            // MODE 1: [NX, D] accumulated with atomics
-  int chunk;           // streamed vectors per workgroup (multiple of 64)
-};
 
 template <int D>
 __device__ __forceinline__ int yoff(int row, int ch) {  // byte offset of 16-byte chunk ch of LDS row `row`
@@ -290,7 +274,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
 // streamed vectors per workgroup for about `target` workgroups.  Forward (one partial per (chunk, x)): 1024.  Backward: every
 // workgroup adds its whole 256 x D partial gradient with atomics, so fewer, longer chunks pay (c2, S = 4600: 0.103 -> 0.078 ms per
 // step with 512; 384 and fewer lose on the large tables: S = 1M backward 6.4 ms with 512, 7.5 ms with 384)
-static inline int mfma_chunk(int64_t nx, int64_t ny, int target = 1024) {
+int mfma_chunk(int64_t nx, int64_t ny, int target) {
   const int64_t xt = fh_cdiv(nx, 256);
   int64_t want = fh_cdiv(target, xt);
   int64_t chunk = fh_cdiv(fh_cdiv(ny, want), 64) * 64;
@@ -307,7 +291,7 @@ int64_t disc_mfma_ws_bytes(int64_t B, int64_t S) {
 }
 
 int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
-                  int64_t B, int64_t S, int64_t D, hipStream_t st) {
+                  int64_t B, int64_t S, int64_t D, int lp, hipStream_t st) {
   DiscMfmaArgs a = {};
   a.X = q;
   a.Y = table;
@@ -321,7 +305,9 @@ int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_
   a.chunk = mfma_chunk(B, S);
   *nchunks = (int)fh_cdiv(S, a.chunk);
   dim3 grid((unsigned)*nchunks, (unsigned)fh_cdiv(B, 256));
-  if (D == 32)
+  if (lp && D == 32)
+    disc_lp_launch(a, 0, grid, st);
+  else if (D == 32)
     hipLaunchKernelGGL((disc_mfma_kernel<32, 0>), grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((disc_mfma_kernel<16, 0>), grid, dim3(256), 0, st, a);
@@ -330,7 +316,7 @@ int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_
 
 int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
                   const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, int64_t B, int64_t S,
-                  int64_t D, hipStream_t st) {
+                  int64_t D, int lp, hipStream_t st) {
   DiscMfmaArgs a = {};
   a.c = c;
   a.idx = idx;
@@ -348,7 +334,9 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
     a.G = dq;
     a.chunk = mfma_chunk(B, S, 512);
     dim3 grid((unsigned)fh_cdiv(S, a.chunk), (unsigned)fh_cdiv(B, 256));
-    if (D == 32)
+    if (lp && D == 32)
+      disc_lp_launch(a, 1, grid, st);
+    else if (D == 32)
       hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((disc_mfma_kernel<16, 1>), grid, dim3(256), 0, st, a);
@@ -364,7 +352,9 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
     a.G = dtable;
     a.chunk = mfma_chunk(S, B, 512);
     dim3 grid((unsigned)fh_cdiv(B, a.chunk), (unsigned)fh_cdiv(S, 256));
-    if (D == 32)
+    if (lp && D == 32)
+      disc_lp_launch(a, 1, grid, st);
+    else if (D == 32)
       hipLaunchKernelGGL((disc_mfma_kernel<32, 1>), grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((disc_mfma_kernel<16, 1>), grid, dim3(256), 0, st, a);

@@ -3,6 +3,7 @@
 //   log-sum-exp cross-entropy over the mu2 table (:119-122), fused Adam (train_model.py:409-411),
 //   layout utilities.
 #include "common.h"
+#include "disc_mfma.h"
 #include <cstdlib>
 
 namespace fh {
@@ -666,15 +667,8 @@ extern "C" int fhvae_elbo_bwd(const fhvae_elbo_bwd_desc* d, void* stream) {
   return fh_launch_status();
 }
 
-namespace fh {  // disc_mfma.hip: the matrix-core form for large (B x S), D == 32
-bool disc_mfma_supported(int64_t B, int64_t S, int64_t D);
-int64_t disc_mfma_ws_bytes(int64_t B, int64_t S);
-int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
-                  int64_t B, int64_t S, int64_t D, hipStream_t st);
-int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
-                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, int64_t B, int64_t S,
-                  int64_t D, hipStream_t st);
-}  // namespace fh
+// disc_mfma.hip / disc_lp.hip: the matrix-core forms for large (B x S), D == 32 (declared in disc_mfma.h)
+  // namespace fh
 
 extern "C" int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S) {
   if (B <= 0 || S <= 0) return 0;
@@ -695,7 +689,8 @@ extern "C" int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S) {
 
 extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float inv_two_var,
                                   float* row_max, float* row_sumexp, float* tgt_logit, float* ce_mean, void* ws, int64_t B,
-                                  int64_t S, int64_t D, void* stream) {
+                                  int64_t S, int64_t D, int dtype, void* stream) {
+  if (dtype != FHVAE_F32 && dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
   FH_CHECK_PTR(q);
   FH_CHECK_PTR(table);
   FH_CHECK_PTR(idx);
@@ -712,7 +707,7 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
   float2* part = (float2*)ws;
   int e, own_excluded = 0;
   if (disc_mfma_supported(B, S, D) && !getenv("FHVAE_DISC_VALU")) {
-    e = disc_mfma_fwd(q, table, idx, row0, inv_two_var, part, &p.nchunks, B, S, D, st);
+    e = disc_mfma_fwd(q, table, idx, row0, inv_two_var, part, &p.nchunks, B, S, D, dtype == FHVAE_BF16, st);
     own_excluded = 1;
   } else {
     dim3 grid((unsigned)p.btiles, (unsigned)p.nchunks);
@@ -760,7 +755,8 @@ extern "C" int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp,
 
 extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float inv_two_var,
                                   const float* row_max, const float* row_sumexp, const float* g_scale, float g_mul,
-                                  float* dq, float* dtable, void* ws, int64_t B, int64_t S, int64_t D, void* stream) {
+                                  float* dq, float* dtable, void* ws, int64_t B, int64_t S, int64_t D, int dtype, void* stream) {
+  if (dtype != FHVAE_F32 && dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
   FH_CHECK_PTR(q);
   FH_CHECK_PTR(table);
   FH_CHECK_PTR(idx);
@@ -778,7 +774,8 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
       hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
       if (he != hipSuccess) return (int)he;
     }
-    int e = disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, B, S, D, st);
+    int e = disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, B, S, D,
+                          dtype == FHVAE_BF16, st);
     if (e) return e;
     if (dq || dtable) {
       DISC_DISPATCH(D, hipLaunchKernelGGL((disc_own_bwd_kernel<DD>), dim3((unsigned)fh_cdiv(B * (DD / 4), 256)), dim3(256), 0, st, q,

@@ -33,6 +33,7 @@ class HipBackend:
 
         hb.load_library()
         self.hb = hb
+        self.lp = False  # bf16 compute mode of the model (DistributedFHVAE sets it): K5 on the split-operand bf16 MFMA kernels
 
     # A rank whose shard is empty (more ranks than rows: row0 == row1 == S) still takes part in every collective with the
     # neutral element of each reduction; the kernels are never launched on zero rows.
@@ -51,7 +52,7 @@ class HipBackend:
             n = q_all.shape[0]
             z = torch.zeros(n, device=q_all.device, dtype=torch.float32)
             return torch.full_like(z, -float("inf")), z, z.clone()
-        rmax, rsum, tgt, _ = self.hb.raw_disc_fwd(q_all, shard, idx_all, row0=row0, want_ce=False)
+        rmax, rsum, tgt, _ = self.hb.raw_disc_fwd(q_all, shard, idx_all, row0=row0, want_ce=False, lp=self.lp)
         return rmax, rsum, tgt
 
     def disc_rescale(self, rmax, rsum, m):
@@ -64,7 +65,7 @@ class HipBackend:
     def disc_bwd(self, q_all, shard, idx_all, row0, m, s, g, g_mul, need_dq, need_dt):
         if shard.shape[0] == 0:
             return (torch.zeros_like(q_all) if need_dq else None), (torch.zeros_like(shard) if need_dt else None)
-        return self.hb.raw_disc_bwd(q_all, shard, idx_all, m, s, g, g_mul, row0=row0, need_dq=need_dq, need_dt=need_dt)
+        return self.hb.raw_disc_bwd(q_all, shard, idx_all, m, s, g, g_mul, row0=row0, need_dq=need_dq, need_dt=need_dt, lp=self.lp)
 
 
 class ShardCtx:
@@ -208,6 +209,7 @@ class DistributedFHVAE:
             raise ValueError("build the model with num_seqs= so the table exists")
         self.model = model
         self.sh = ShardCtx(model.mu2_table.shape[0], group, HipBackend())
+        self.sh.backend.lp = getattr(model, "compute_dtype", "f32") == "bf16"
         full = model.mu2_table.data
         self.shard = nn.Parameter(full[self.sh.row0:self.sh.row1].clone())
         model.mu2_table = None  # the full table is dropped: only the shard stays resident

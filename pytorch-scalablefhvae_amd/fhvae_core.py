@@ -28,7 +28,7 @@ class LocalTableOps:
         return table, hb.mu2_gather(table, mu_idx)
 
     def disc(self, z2_mu, table, mu_idx):
-        return hb.disc_lse(z2_mu, table, mu_idx)
+        return hb.disc_lse(z2_mu, table, mu_idx, lp=getattr(self.model, "compute_dtype", "f32") == "bf16")
 
 
 class FHVAEBase(nn.Module):

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
 
 F32, BF16 = 0, 1
 MAX_LAYERS = 4
-ABI_VERSION = 3  # FHVAE_ABI_VERSION of include/fhvae_hip.h
+ABI_VERSION = 4  # FHVAE_ABI_VERSION of include/fhvae_hip.h
 #: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
 INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
@@ -98,8 +98,8 @@ SIGNATURES = {
     "fhvae_elbo_fwd": (C.c_int, [C.POINTER(ElboDesc), _vp]),
     "fhvae_elbo_bwd": (C.c_int, [C.POINTER(ElboBwdDesc), _vp]),
     "fhvae_disc_lse_ws_bytes": (_i64, [_i64, _i64]),
-    "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
-    "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
+    "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
     "fhvae_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "fhvae_segment_gather": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "fhvae_mu2_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
@@ -856,7 +856,8 @@ def fused_loss(lower_bound, log_qy, alpha):
     return _FusedLoss.apply(lower_bound, log_qy, float(alpha))
 
 
-def raw_disc_fwd(q, table, idx, row0=0, want_ce=True):
+def raw_disc_fwd(q, table, idx, row0=0, want_ce=True, lp=False):
+    """lp: the bf16 compute mode's kernels (split-operand bf16 MFMA) where they apply (D = 32, B*S >= 65536)."""
     lib = load_library()
     B, D = q.shape
     S = table.shape[0]
@@ -866,11 +867,11 @@ def raw_disc_fwd(q, table, idx, row0=0, want_ce=True):
     ce = torch.empty((), device=dev, dtype=torch.float32) if want_ce else None
     with _Timed("fhvae_disc_lse_fwd"):
         _check(lib.fhvae_disc_lse_fwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(tgt), _p(ce), _p(ws),
-                                      B, S, D, _stream()), "fhvae_disc_lse_fwd")
+                                      B, S, D, BF16 if lp else F32, _stream()), "fhvae_disc_lse_fwd")
     return rmax, rsum, tgt, ce
 
 
-def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True, need_dt=True, dt_sink=None):
+def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True, need_dt=True, dt_sink=None, lp=False):
     lib = load_library()
     B, D = q.shape
     S = table.shape[0]
@@ -878,7 +879,7 @@ def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True
     dt = dt_sink if dt_sink is not None else (torch.zeros(S, D, device=q.device, dtype=torch.float32) if need_dt else None)
     with _Timed("fhvae_disc_lse_bwd"):
         _check(lib.fhvae_disc_lse_bwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(g_scale), float(g_mul),
-                                      _p(dq), _p(dt), None, B, S, D, _stream()), "fhvae_disc_lse_bwd")
+                                      _p(dq), _p(dt), None, B, S, D, BF16 if lp else F32, _stream()), "fhvae_disc_lse_bwd")
     return dq, (None if dt_sink is not None else dt)
 
 
@@ -904,11 +905,12 @@ class _DiscLse(torch.autograd.Function):
     simple_fhvae.py:119-122, without the (B,S,D) temporaries."""
 
     @staticmethod
-    def forward(ctx, q, table, idx):
+    def forward(ctx, q, table, idx, lp):
         _need_gpu(q, table, idx)
         ctx.sink = _sink(table)
+        ctx.lp = bool(lp)
         q, table = _f32c(q), _f32c(table)
-        rmax, rsum, _, ce = raw_disc_fwd(q, table, idx)
+        rmax, rsum, _, ce = raw_disc_fwd(q, table, idx, lp=ctx.lp)
         ctx.save_for_backward(q, table, idx, rmax, rsum)
         return ce
 
@@ -917,12 +919,13 @@ class _DiscLse(torch.autograd.Function):
         q, table, idx, rmax, rsum = ctx.saved_tensors
         g = _f32c(g).reshape(1)
         dq, dt = raw_disc_bwd(q, table, idx, rmax, rsum, g, 1.0 / q.shape[0], need_dq=ctx.needs_input_grad[0],
-                              need_dt=ctx.needs_input_grad[1], dt_sink=ctx.sink)
-        return dq, dt, None
+                              need_dt=ctx.needs_input_grad[1], dt_sink=ctx.sink, lp=ctx.lp)
+        return dq, dt, None, None
 
 
-def disc_lse(q, table, idx):
-    return _DiscLse.apply(q, table, idx)
+def disc_lse(q, table, idx, lp=False):
+    """lp=True: the bf16 compute mode (models built with compute_dtype='bf16'); default = the f32 parity mode."""
+    return _DiscLse.apply(q, table, idx, bool(lp))
 
 
 def wgrad_bf16_(c, a, b):

@@ -251,3 +251,35 @@ def test_disc_converged_regime(hb, B, S, scale, noise):
     for got, want, n in ((q2.grad, dq64, "dq valu"), (t2.grad, dt64, "dtable valu")):
         err = (got.detach().cpu().double() - want).abs().max().item()
         assert err <= 1e-4 * max(want.abs().max().item(), 1e-6) + 1e-7, (n, err)
+
+
+@pytest.mark.parametrize("B,S,scale,noise", [(2048, 28000, 1.0, None), (256, 4600, 1.0, None), (512, 9000, 3.0, 0.3),
+                                             (300, 5000, 1.0, 0.05), (2048, 100000, 1.0, None)])
+def test_disc_bf16_mode_vs_direct_f64(hb, B, S, scale, noise):
+    """K5 in the bf16 compute mode (hip_binding.disc_lse(..., lp=True): cross terms on bf16 MFMA with hi/lo-split operands,
+    second products with bf16 weights; csrc/disc_lp.hip) against the direct form in float64.  Stated tolerance of that mode:
+    the cross term carries ~2^-16 |q||t| (a logit: ~1e-3 absolute at N(0,1) scale, ~1e-2 at 3x), CE within 2e-3 relative +
+    that resolution; gradients within 1e-2 of their max (bf16 weights: 0.4 % per term).  noise=None: queries unrelated to the
+    table (the start of training); else q = table[idx] + noise * N(0,1) (where training converges)."""
+    torch.manual_seed(B + S + 1)
+    D = 32
+    table = torch.randn(S, D) * scale
+    idx = torch.randint(0, S, (B,))
+    idx[1] = idx[0]
+    q = torch.randn(B, D) * scale if noise is None else table[idx] + noise * torch.randn(B, D)
+    ce64, dq64, dt64 = _disc_oracle_f64(q, table, idx)
+    qd, td = dev(q).requires_grad_(True), dev(table).requires_grad_(True)
+    ce = hb.disc_lse(qd, td, dev(idx), lp=True)
+    ce.backward()
+    resolution = 2.0 ** -16 * 2 * hb.INV_TWO_VAR * (scale * scale * D * 2)
+    assert abs(ce.item() - ce64.item()) <= 2e-3 * abs(ce64.item()) + 4 * resolution, (ce.item(), ce64.item(), resolution)
+    spread = (2 * noise * D ** 0.5) if noise is not None else (2 * scale * D ** 0.5)
+    g_floor = 4 * resolution * 2 * hb.INV_TWO_VAR * spread / B + 1e-9
+    for got, want, n in ((qd.grad, dq64, "dq"), (td.grad, dt64, "dtable")):
+        err = (got.detach().cpu().double() - want).abs().max().item()
+        ref = want.abs().max().item()
+        assert err <= 1e-2 * ref + g_floor, (n, err, ref, g_floor)
+    # and it is the same function of its inputs as the f32 mode up to that tolerance
+    q2, t2 = dev(q).requires_grad_(True), dev(table).requires_grad_(True)
+    ce2 = hb.disc_lse(q2, t2, dev(idx))
+    assert abs(ce2.item() - ce.item()) <= 2e-3 * abs(ce2.item()) + 4 * resolution
