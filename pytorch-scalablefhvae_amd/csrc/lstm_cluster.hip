@@ -1610,11 +1610,11 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
 // weights.  It is a K-split partial sum over the same unit tiles as the recurrent product, so it simply starts the accumulators
 // -- and it does not depend on the exchange, so its 64 MFMAs per wave run while the exchange loads are in flight.  The
 // (T*B x 4H x H) GEMM between the two launches of a net and its f32 (T,B,H) round trip are gone.
-// BLK: the gate gradients are kept ONLY in the blocked form [t][k-step][batch row][32] (the layout of the exchange buffer, with
-// one slot per time step instead of two parities, in the dgates buffer itself): the step's exchange store IS the saved dg, the
-// row-major copy (84 MB written per launch at B = 2048, its LDS image and, with ABOVE, the barrier that protected that image)
-// is gone, the from-above operand of the layer below is read as 1-KB fragments instead of 16 x 64 B at the row stride, and the
-// weight-gradient kernel (wgrad.hip, WgProblem::a_blk_rows) takes its A operand from the blocked layout.
+// BLK: the gate gradients are SAVED in the blocked form [t][k-step][batch row][32] (the layout of the exchange buffer, one slot
+// per time step, in the dgates buffer itself) instead of row-major: the saved copy leaves straight from the registers behind
+// the publish (no LDS image, and with ABOVE no barrier protecting that image), the from-above operand of the layer below is read
+// as 1-KB fragments instead of 16 x 64 B at the row stride, and the weight-gradient kernel (wgrad.hip, WgProblem::a_blk_rows)
+// takes its A operand from the blocked layout.
 template <int H, int RT, bool ABOVE, bool BLK>
 __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
   constexpr int HU = 64, UT = 4;
@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
   auto pack4 = [](const f32x4& v) -> uint2 {
     return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
   };
-  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(BLK ? (const void*)p.dg : (const void*)p.xch);
+  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(p.xch);
   unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
   __syncthreads();  // weights have landed (and every thread has read the join word)
 
@@ -1775,8 +1775,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
       uint4 a[RT][KPW];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        // BLK: the slot of time t + 1 (written by the members in the previous step); else the previous step's parity
-        const int64_t base = (xch_off(BLK ? t + 1 : (s - 1) & 1, 0, 1, KS, kp * KPW, B, rowc[rt]) + q * 8) * 2;
+        const int64_t base = (xch_off((s - 1) & 1, 0, 1, KS, kp * KPW, B, rowc[rt]) + q * 8) * 2;
 #pragma unroll
         for (int j = 0; j < KPW; ++j) a[rt][j] = load_sc1(dg_rs, base + j * (B * 64));
       }
@@ -1831,10 +1830,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
         for (int g = 0; g < 4; ++g) {
           dgs[rt][g] += dp[g];
           dpk[rt][g] = pack4(dp[g]);
-          if constexpr (BLK) {  // slot t of the blocked dg: what the members wait for AND what is saved
-            *(uint2*)(p.dg + xch_off(t, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];
-          } else {
-            *(uint2*)(p.xch + xch_off(s & 1, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];  // what the members wait for
+          *(uint2*)(p.xch + xch_off(s & 1, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];  // what the members wait for
+          if constexpr (!BLK) {
             if constexpr (ABOVE)
               *(uint2*)stg_alias(wave, rt, r, g, q * 8) = dpk[rt][g];
             else
@@ -1847,6 +1844,18 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
     if (s + 1 < T) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));  // (its barrier also frees Part)
     else __syncthreads();
     CL_TLOG(s * 8 + 4);
+    // BLK: the saved copy is the same blocked image, in slot t of the dgates buffer, stored from the registers behind the
+    // publish (the exchange itself stays in the two L2-hot parity slots: with the exchange in per-step slots the top layer's
+    // launch took 124 us against 108)
+    if constexpr (BLK) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        if (row[rt] < rend) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *(uint2*)(p.dg + xch_off(t, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];
+        }
+    }
     // the row-major copy the weight-gradient contractions read leaves through the LDS image as whole 128-byte lines (a lane's
     // own values are 8-byte pieces of 16 different lines per instruction)
     if constexpr (!BLK) {
@@ -2120,7 +2129,9 @@ bool cluster_dg_blocked(const fhvae_lstm_bwd_desc* bd) {
   const fhvae_lstm_desc* d = &bd->f;
   if (!cluster_eligible(d) || cluster_form(d) != 1 || d->H != 256) return false;
   if (!(d->L == 1 || bd->ws_below) || getenv("FHVAE_NO_LAYERWISE") || getenv("FHVAE_NO_LAYER_KS") || getenv("FHVAE_NO_FUSE_ABOVE")) return false;
-  if (getenv("FHVAE_NO_WGRAD") || getenv("FHVAE_NO_DG_BLOCKED")) return false;
+  // opt-in: measured (c3, B = 2048, interleaved A/B on one device) 930-933 k segments/s with it against 942-945 k without --
+  // the 8-byte stores of the blocked copy cost more than the LDS image + whole-line stores of the row-major copy save
+  if (getenv("FHVAE_NO_WGRAD") || !getenv("FHVAE_DG_BLOCKED")) return false;
   if (d->B % 64 != 0 || d->T < 2 || d->I % 8 != 0) return false;
   if ((int64_t)d->T * d->B * 4 * d->H * 2 >= (1LL << 30)) return false;  // wgrad's 32-bit buffer offsets
   return true;
