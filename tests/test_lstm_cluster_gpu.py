@@ -144,3 +144,32 @@ def test_from_above_term_fused_or_by_gemm(hb, B, T, Ic):
     if Ic:
         err = (a[3] - b[3]).abs().max().item()
         assert err <= 2e-3 * b[3].abs().max().item() + 1e-6, ("d_xc", err)
+
+
+@pytest.mark.parametrize("B,T,I,Ic", [(2048, 6, 80, 32), (1024, 3, 0, 64)])
+def test_blocked_dg_experiment_matches_default(hb, B, T, I, Ic):
+    """FHVAE_DG_BLOCKED=1 (opt-in experiment): the per-layer backward saves dg in the blocked exchange layout, the
+    fused from-above term and wgrad.hip read that layout.  Same gradients as the default row-major form (bf16 dg either way:
+    identical values, different addresses; the split-K atomics of the weight gradients reorder the f32 sums)."""
+    torch.manual_seed(B + T)
+    H, L = 256, 2
+    lstm = torch.nn.LSTM(I + Ic, H, L, batch_first=True)
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    params = [getattr(lstm, n).detach().cuda() for n in names]
+    x_tm = torch.randn(T, B, I).cuda() if I else None
+    xc = torch.randn(B, Ic).cuda() if Ic else None
+    g_out, g_hn = torch.randn(T, B, H).cuda(), torch.randn(B, L * H).cuda()
+    res = []
+    for blocked in (False, True):
+        if blocked:
+            os.environ["FHVAE_DG_BLOCKED"] = "1"
+        try:
+            res.append(_run(hb, x_tm, xc, T, params, g_out, g_hn, cluster=True))
+        finally:
+            os.environ.pop("FHVAE_DG_BLOCKED", None)
+    assert hb.lstm_sync_status() == 0
+    for n, ga, gb in zip(names, res[0][2], res[1][2]):
+        scale = ga.abs().max().item() + 1e-30
+        assert (ga - gb).abs().max().item() <= 1e-4 * scale, (n, (ga - gb).abs().max().item(), scale)
+    if Ic:
+        assert (res[0][3] - res[1][3]).abs().max().item() <= 1e-5 * (res[0][3].abs().max().item() + 1e-30)
