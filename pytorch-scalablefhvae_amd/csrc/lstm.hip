@@ -16,6 +16,7 @@
 #include "gemm_launch.h"
 #include "lstm_cluster.h"
 #include "wgrad.h"
+#include <algorithm>
 #include <vector>
 #include "trace.h"
 #include <cstdlib>
@@ -648,7 +649,8 @@ constexpr int64_t kWgradMinK = 1024;  // shorter contractions stay on the generi
 // `wq` (bf16 only): long contractions that meet wgrad.hip's preconditions are appended to it instead of being launched; the
 // caller launches everything it has collected (possibly from several nets) as one grouped launch (launch_wgrad).
 template <typename T>
-static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStream_t st, std::vector<WgProblem>* wq = nullptr) {
+static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStream_t st, std::vector<WgProblem>* wq = nullptr,
+                            std::vector<GemmParams>* fq = nullptr) {
   const fhvae_lstm_desc* d = &bd->f;
   const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
   const int L = d->L;
@@ -706,8 +708,12 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
           grp[ng++] = wgrad(dgl, G, op.x, I, T_ * B, bd->dw_ih[0], K0, I);
         if (Ic > 0) {  // the time-constant input's part: f32 running sum over t of dg (B rows)
           GemmParams p = wgrad(bd->dgsum, G, d->xc, Ic, B, bd->dw_ih[0] + I, K0, Ic);
-          e = launch_gemm(p, FHVAE_F32, st);
-          if (e) return e;
+          if (fq) {  // several nets at once: these small f32 contractions go out as one grouped launch too
+            fq->push_back(p);
+          } else {
+            e = launch_gemm(p, FHVAE_F32, st);
+            if (e) return e;
+          }
         }
       }
     }
@@ -789,6 +795,7 @@ extern "C" int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* bd
   if (n < 0) return FHVAE_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   std::vector<WgProblem> wq;
+  std::vector<GemmParams> fq;  // the f32 (B-row) contractions of the time-constant inputs
   const bool use_wq = !getenv("FHVAE_NO_WGRAD");
   for (int i = 0; i < n; ++i) {
     const fhvae_lstm_bwd_desc* bd = bds[i];
@@ -801,8 +808,12 @@ extern "C" int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* bd
     if (d->dtype == FHVAE_F32) {
       e = lstm_param_grads<float>(bd, ops_f32(d), st);
     } else {
-      e = lstm_param_grads<u16>(bd, ops_bf16(d), st, use_wq ? &wq : nullptr);
+      e = lstm_param_grads<u16>(bd, ops_bf16(d), st, use_wq ? &wq : nullptr, &fq);
     }
+    if (e) return e;
+  }
+  for (size_t i = 0; i < fq.size(); i += kMaxGroup) {
+    const int e = launch_gemm_group(fq.data() + i, (int)std::min<size_t>(kMaxGroup, fq.size() - i), FHVAE_F32, st);
     if (e) return e;
   }
   return launch_wgrad(wq.data(), (int)wq.size(), st);
