@@ -14,6 +14,7 @@
 // same (segment, unit)) and applies sigmoid/tanh + the cell update in registers: the (B,4H)
 // pre-activations never touch HBM.
 #include "gemm_launch.h"
+#include "lstm_cell.h"
 #include "lstm_cluster.h"
 #include "wgrad.h"
 #include <algorithm>
@@ -24,31 +25,6 @@
 namespace fh {
 
 constexpr int kCH = 32;  // 512-byte panels: the step GEMMs are latency-bound, pay the latency once per panel
-
-// ---------------------------------------------------------------------------------------------
-// forward cell
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-struct FwdJob {
-  Seg seg[2];           // seg0: layer input x W_ih (l >= 1), seg1: h_{t-1} x W_hh (t >= 1); K = 0 when absent
-  const float* pre;     // [B,4H] additive term incl. biases (l == 0) or NULL
-  int64_t pre_ld;
-  const float* bias_a;  // [4H] (l >= 1) or NULL
-  const float* bias_b;
-  const float* c_prev;  // [B,H] or NULL (t == 0)
-  float* c_out;         // [B,H]
-  T* h_out;             // [B,H] operand dtype
-  float* h_out_f32;     // optional f32 copy of h (top layer in bf16 mode: feeds the f32 Gaussian head)
-  T* gates_out;         // [B,4H] activated i,f,g,o (operand dtype: bf16 halves the cell's dominant HBM write)
-  float* hn_out;        // optional slot in the (B, L*H) final-state buffer (t == T-1)
-  int64_t hn_ld;
-};
-template <typename T>
-struct FwdJobs {
-  int B, H;
-  int glds;  // use the LDS-DMA main loop where the tile allows it
-  FwdJob<T> job[FHVAE_MAX_LAYERS];
-};
 
 // virtual column n of the gate matrix -> physical weight row: tiles of 64 = 4 gates x 16 units
 struct GateRowMap {
@@ -169,32 +145,6 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(FwdJobs<T> jobs
       if (J.hn_out) J.hn_out[(int64_t)row * J.hn_ld + unit] = h;
     }
 }
-
-// ---------------------------------------------------------------------------------------------
-// backward cell: dh_t = dg^l_{t+1} . W_hh[l] + dg^{l+1}_t . W_ih[l+1] (+ external), then the
-// elementwise LSTM backward in the epilogue -> dg^l_t (pre-activation gate gradients)
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-struct BwdJob {
-  Seg seg[2];
-  const float* ext;   // [B,H] external dh (top layer: d_hs_top[t]) or NULL
-  int64_t ext_ld;
-  const float* ext2;  // [B,H] slot of d_hn (t == T-1) or NULL
-  int64_t ext2_ld;
-  const T* gates;       // [B,4H] saved activations (operand dtype)
-  const float* c_prev;  // [B,H] or NULL
-  const float* c_cur;   // [B,H]
-  float* dc;            // [B,H] running dL/dc (already multiplied by f of the later step)
-  int first;            // 1 at t == T-1: dc input is zero
-  T* dg_out;            // [B,4H]
-  float* dgsum;         // optional [B,4H] running f32 sum over t (layer 0 with a time-constant input)
-};
-template <typename T>
-struct BwdJobs {
-  int B, H;
-  int glds;
-  BwdJob<T> job[FHVAE_MAX_LAYERS];
-};
 
 // Tile shapes: <32,32,2,2> and <128,64,4,1> (very large batches only, as for the forward cell).
 template <typename T, int BM, int BN, int WM, int WN, int CH>
@@ -445,6 +395,15 @@ static int cast_operands(const fhvae_lstm_desc* d, hipStream_t st) {
   return fh_launch_status();
 }
 
+// the large-tile bf16 cells (lstm_cell.hip) take a wavefront step once it offers them about a workgroup per CU
+// (FHVAE_BIG_CELLS=0/1 overrides)
+static bool big_cells(int64_t B, int64_t H) {
+  const char* ev = getenv("FHVAE_BIG_CELLS");  // read per call: the tests flip it
+  const int env = ev ? atoi(ev) : -1;
+  if (env >= 0) return env != 0;
+  return (B / 128) * (H / 64) >= 96;
+}
+
 template <typename T>
 static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t st) {
   const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
@@ -526,7 +485,14 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     // (measured at B = 2048, H = 512, bf16: 128x128 tiles 1.3-1.8 ms per net forward against 1.0-1.3 ms with 64x64: the
     //  heuristic stays "B >= 16384"; FHVAE_FWD_TILE overrides for experiments)
     const bool big_fwd = fwd_tile ? fwd_tile == 128 : B >= 16384;
-    if (big_fwd) {
+    bool cell_big = false;
+    if constexpr (sizeof(T) == 2) cell_big = big_cells(B, H) && cell_fwd_big_ok(jobs, nj);
+    if (cell_big) {
+      if constexpr (sizeof(T) == 2) {
+        const int e = launch_cell_fwd_big(jobs, nj, st);
+        if (e) return e;
+      }
+    } else if (big_fwd) {
       dim3 grid((unsigned)fh_cdiv(B, 128), (unsigned)fh_cdiv(H, 32), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 128, 128, 2, 2, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else if (B >= 1024) {
@@ -621,7 +587,14 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     static const int bwd_tile = getenv("FHVAE_BWD_TILE") ? atoi(getenv("FHVAE_BWD_TILE")) : 0;
     // (measured at B = 2048, H = 512, bf16: 64x64 tiles 2.4 ms per net backward, 32x32 2.2-2.3 ms: no gain from larger tiles)
     const int bt = bwd_tile ? bwd_tile : (B >= 16384 ? 128 : 32);
-    if (bt == 128) {
+    bool cell_big = false;
+    if constexpr (!kF32) cell_big = big_cells(B, H) && cell_bwd_big_ok(jobs, nj);
+    if (cell_big) {
+      if constexpr (!kF32) {
+        const int e = launch_cell_bwd_big(jobs, nj, st);
+        if (e) return e;
+      }
+    } else if (bt == 128) {
       dim3 grid((unsigned)fh_cdiv(B, 128), (unsigned)fh_cdiv(H, 64), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 128, 64, 4, 1, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else if (bt == 64) {
