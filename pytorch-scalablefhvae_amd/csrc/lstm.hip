@@ -404,6 +404,61 @@ static bool big_cells(int64_t B, int64_t H) {
   return (B / 128) * (H / 64) >= 96;
 }
 
+// the forward jobs of wavefront step w; `big`: for the large-tile cells, which multiply layer 0's input themselves (no `pre`)
+template <typename T>
+static FwdJobs<T> fwd_jobs(const fhvae_lstm_desc* d, const Ops<T>& op, int64_t w, bool big, int& nj) {
+  const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H, K0 = I + Ic;
+  const int L = d->L;
+  const int64_t pre_tstride = I > 0 ? B * 4 * H : 0;
+  T* hs = (T*)d->hs;
+  const T* w0 = op.w_ih[0];
+  FwdJobs<T> jobs = {};
+  jobs.B = (int)B;
+  jobs.H = (int)H;
+  jobs.glds = getenv("FHVAE_NO_GLDS") ? 0 : 1;
+  nj = 0;
+  for (int l = 0; l < L; ++l) {
+    const int64_t t = w - l;
+    if (t < 0 || t >= T_) continue;
+    FwdJob<T>& J = jobs.job[nj++];
+    const int64_t lt = (int64_t)l * T_ + t;
+    if (l > 0) J.seg[0] = Seg{hs + ((int64_t)(l - 1) * T_ + t) * B * H, H, 1, op.w_ih[l], H, 1, (int)H, 0};
+    if (t > 0) J.seg[1] = Seg{hs + (lt - 1) * B * H, H, 1, op.w_hh[l], H, 1, (int)H, 0};
+    if (l == 0 && !big) {
+      J.pre = d->pre + t * pre_tstride;
+      J.pre_ld = 4 * H;
+    } else {
+      J.bias_a = d->b_ih[l];
+      J.bias_b = d->b_hh[l];
+    }
+    if (l == 0 && big) {
+      if (I > 0) J.xseg[0] = Seg{op.x + t * B * I, I, 1, w0, K0, 1, (int)I, 0};
+      if (Ic > 0) J.xseg[1] = Seg{op.xc, Ic, 1, w0 + I, K0, 1, (int)Ic, 0};
+    }
+    J.c_prev = t > 0 ? d->cs + (lt - 1) * B * H : nullptr;
+    J.c_out = d->cs + lt * B * H;
+    J.h_out = hs + lt * B * H;
+    if (l == L - 1 && d->hs_top_f32) J.h_out_f32 = d->hs_top_f32 + t * B * H;
+    J.gates_out = (T*)d->gates + lt * B * 4 * H;
+    if (d->hn && t == T_ - 1) {
+      J.hn_out = d->hn + (int64_t)l * H;
+      J.hn_ld = (int64_t)L * H;
+    }
+  }
+  return jobs;
+}
+
+// every wavefront step of the sequence meets the large-tile cells' preconditions
+static bool cell_fwd_plan_ok(const fhvae_lstm_desc* d, const Ops<u16>& op) {
+  for (int64_t w = 0; w < d->T + d->L - 1; ++w) {
+    int nj = 0;
+    const FwdJobs<u16> jobs = fwd_jobs<u16>(d, op, w, true, nj);
+    if (!cell_fwd_big_ok(jobs, nj)) return false;
+  }
+  return true;
+}
+static bool cell_fwd_plan_ok(const fhvae_lstm_desc*, const Ops<float>&) { return false; }
+
 template <typename T>
 static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t st) {
   const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
@@ -418,7 +473,10 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     fold = cluster && cluster_can_fold(d);
     xc_in = cluster && cluster_xc_in_kernel(d);
   }
-  if (!(fold && Ic == 0) && !xc_in) {
+  // large-tile step cells (lstm_cell.hip; all steps of the sequence or none): they multiply layer 0's input themselves
+  bool cell_big = false;
+  if constexpr (sizeof(T) == 2) cell_big = !cluster && big_cells(B, H) && cell_fwd_plan_ok(d, op);
+  if (!cell_big && !(fold && Ic == 0) && !xc_in) {
     GemmParams p = {};
     int s = 0;
     if (I > 0 && !fold) p.seg[s++] = Seg{op.x, I, 1, w0, K0, 1, (int)I, 0};
@@ -443,41 +501,13 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
       return cluster_fwd(d, cw, st);
     }
   }
-  const int64_t pre_tstride = I > 0 ? B * 4 * H : 0;
-  T* hs = (T*)d->hs;
   // ---- wavefront over (layer, time)
   for (int64_t w = 0; w < T_ + L - 1; ++w) {
-    FwdJobs<T> jobs = {};
-    jobs.B = (int)B;
-    jobs.H = (int)H;
-    jobs.glds = getenv("FHVAE_NO_GLDS") ? 0 : 1;
     int nj = 0;
-    for (int l = 0; l < L; ++l) {
-      const int64_t t = w - l;
-      if (t < 0 || t >= T_) continue;
-      FwdJob<T>& J = jobs.job[nj++];
-      const int64_t lt = (int64_t)l * T_ + t;
-      if (l > 0) J.seg[0] = Seg{hs + ((int64_t)(l - 1) * T_ + t) * B * H, H, 1, op.w_ih[l], H, 1, (int)H, 0};
-      if (t > 0) J.seg[1] = Seg{hs + (lt - 1) * B * H, H, 1, op.w_hh[l], H, 1, (int)H, 0};
-      if (l == 0) {
-        J.pre = d->pre + t * pre_tstride;
-        J.pre_ld = 4 * H;
-      } else {
-        J.bias_a = d->b_ih[l];
-        J.bias_b = d->b_hh[l];
-      }
-      J.c_prev = t > 0 ? d->cs + (lt - 1) * B * H : nullptr;
-      J.c_out = d->cs + lt * B * H;
-      J.h_out = hs + lt * B * H;
-      if (l == L - 1 && d->hs_top_f32) J.h_out_f32 = d->hs_top_f32 + t * B * H;
-      J.gates_out = (T*)d->gates + lt * B * 4 * H;
-      if (d->hn && t == T_ - 1) {
-        J.hn_out = d->hn + (int64_t)l * H;
-        J.hn_ld = (int64_t)L * H;
-      }
-    }
+    const FwdJobs<T> jobs = fwd_jobs(d, op, w, cell_big, nj);
     double fl = 0;
-    for (int j = 0; j < nj; ++j) fl += 2.0 * B * 4 * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
+    for (int j = 0; j < nj; ++j)
+      fl += 2.0 * B * 4 * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K + jobs.job[j].xseg[0].K + jobs.job[j].xseg[1].K);
     const int ts = trace_begin(st, kTraceFwdCell, fl);
     // large tiles (half the L2 -> LDS operand bytes per FLOP) only pay once they still give >= 2 workgroups per CU (see
     // gemm.hip): B >= 16384 at H = 256, B >= 2048 at H = 512 (configs[3]: 2048 workgroups of 64x64 pulled 14 TB/s from L2)
@@ -485,8 +515,6 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     // (measured at B = 2048, H = 512, bf16: 128x128 tiles 1.3-1.8 ms per net forward against 1.0-1.3 ms with 64x64: the
     //  heuristic stays "B >= 16384"; FHVAE_FWD_TILE overrides for experiments)
     const bool big_fwd = fwd_tile ? fwd_tile == 128 : B >= 16384;
-    bool cell_big = false;
-    if constexpr (sizeof(T) == 2) cell_big = big_cells(B, H) && cell_fwd_big_ok(jobs, nj);
     if (cell_big) {
       if constexpr (sizeof(T) == 2) {
         const int e = launch_cell_fwd_big(jobs, nj, st);
@@ -540,6 +568,7 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     }
   }
   T* dg = (T*)bd->dgates;
+  bool big_any = false, big_all = true;
   // f32: the weights are read untransposed as KM operands; bf16: the transposed copies [H,4H] are KC operands.
   for (int64_t w = 0; w < T_ + L - 1; ++w) {
     BwdJobs<T> jobs = {};
@@ -610,6 +639,15 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     trace_end(st, ts);
     int e = fh_launch_status();
     if (e) return e;
+    big_any = big_any || cell_big;
+    big_all = big_all && cell_big;
+  }
+  if constexpr (!kF32) {
+    // the large-tile cells leave the time sum of layer 0's gate gradients to one pass over the saved bf16 dgates
+    if (big_any && Ic > 0) {
+      if (!big_all) return FHVAE_ERR_SHAPE;  // (the predicate is the same for every step of a sequence)
+      return launch_cell_dgsum((const u16*)dg, bd->dgsum, (int)T_, B * 4 * H, st);
+    }
   }
   return FHVAE_OK;
 }

@@ -11,6 +11,8 @@ namespace fh {
 template <typename T>
 struct FwdJob {
   Seg seg[2];           // seg0: layer input x W_ih (l >= 1), seg1: h_{t-1} x W_hh (t >= 1); K = 0 when absent
+  Seg xseg[2];          // large-tile cells only (layer 0), directly behind seg[]: x_t x W_ih[0][:, :I] and xc x W_ih[0][:, I:], K any
+                        // multiple of 8 -- the cell multiplies the layer's input itself instead of reading a precomputed `pre`
   const float* pre;     // [B,4H] additive term incl. biases (l == 0) or NULL
   int64_t pre_ld;
   const float* bias_a;  // [4H] (l >= 1) or NULL
@@ -22,7 +24,6 @@ struct FwdJob {
   T* gates_out;         // [B,4H] activated i,f,g,o (operand dtype: bf16 halves the cell's dominant HBM write)
   float* hn_out;        // optional slot in the (B, L*H) final-state buffer (t == T-1)
   int64_t hn_ld;
-  Seg xseg;             // large-tile cells only: x_t x W_ih[0][:, :I] (K = I, any multiple of 8) multiplied by the cell itself
 };
 template <typename T>
 struct FwdJobs {
@@ -62,6 +63,8 @@ struct BwdJobs {
 bool cell_fwd_big_ok(const FwdJobs<u16>& jobs, int nj);
 bool cell_bwd_big_ok(const BwdJobs<u16>& jobs, int nj);
 int launch_cell_fwd_big(const FwdJobs<u16>& jobs, int nj, hipStream_t st);
-int launch_cell_bwd_big(const BwdJobs<u16>& jobs, int nj, hipStream_t st);
+int launch_cell_bwd_big(const BwdJobs<u16>& jobs, int nj, hipStream_t st);  // ignores BwdJob::dgsum: launch_cell_dgsum after the loop
+// out[n] (f32) = sum over t of dg[t][n] (bf16), n = B * 4H a multiple of 8
+int launch_cell_dgsum(const u16* dg, float* out, int T, int64_t n, hipStream_t st);
 
 }  // namespace fh

@@ -12,6 +12,7 @@
 // simple_fhvae.py:160-164, :186-190, :240-244 stand).
 #include "lstm_cell.h"
 
+#include <cstddef>
 #include <cstdlib>
 
 namespace fh {
@@ -86,6 +87,32 @@ __device__ __forceinline__ void cell_mainloop(f32x4 (&acc)[RA / 32][RB / 32], in
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead pieces (zeros) land before the LDS goes back
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef float __attribute__((address_space(3))) * cell_lds_f;
+typedef f32x4v __attribute__((address_space(3))) * cell_lds_f4;
+
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ void unpack_bf8(const u32x4v v, float (&o)[8]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[2 * k] = __builtin_bit_cast(float, v[k] << 16);
+    o[2 * k + 1] = __builtin_bit_cast(float, v[k] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void ld8(const float* p, float (&o)[8]) {
+  const f32x4v a = *(const f32x4v*)p, b = *(const f32x4v*)(p + 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = a[k], o[4 + k] = b[k];
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+  *(f32x4v*)p = f32x4v{v[0], v[1], v[2], v[3]};
+  *(f32x4v*)(p + 4) = f32x4v{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void st8_bf(u16* p, const float (&v)[8]) {
+  *(u32x4v*)p = u32x4v{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+}
+
 // k-step -> (segment, byte offset inside the row)
 struct CellSegs {
   __amdgpu_buffer_rsrc_t a[2], b[2];
@@ -110,26 +137,25 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
   const int wm = wave >> 1, wn = wave & 1;
   const int i = lane & 15, gq = lane >> 4;
 
-  CellSegs sg;
-  unsigned va[2][4], vb[2][4];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const Seg& S = J.seg[s];
-    const bool on = S.K > 0;
-    sg.a[s] = cell_rsrc(on ? (const u16*)S.A + (int64_t)m0 * S.lda : nullptr, (int64_t)BM * S.lda * 2);
-    sg.b[s] = cell_rsrc(on ? S.B : nullptr, (int64_t)4 * H * S.ldb * 2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = (wave * 4 + q) * 8 + (lane >> 3);  // image row
-      const int c = (lane & 7) ^ (row & 7);              // logical chunk that lands in physical chunk lane & 7
-      va[s][q] = (unsigned)row * (unsigned)(S.lda * 2) + (unsigned)c * 16u;
-      // image row j = wn' * 64 + g * 16 + i'  <->  weight row g * H + u0 + wn' * 16 + i'
-      const int wrow = ((row >> 4) & 3) * H + u0 + (row >> 6) * 16 + (row & 15);
-      vb[s][q] = (unsigned)wrow * (unsigned)(S.ldb * 2) + (unsigned)c * 16u;
-    }
-  }
-  sg.n0 = J.seg[0].K / kCellBK;
-  sg.n = sg.n0 + J.seg[1].K / kCellBK;
+  // Up to four K segments: h^{l-1}_t . W_ih[l], h^l_{t-1} . W_hh[l], and for layer 0 x_t . W_ih[0][:, :I], xc . W_ih[0][:, I:]
+  // (any K that is a multiple of 8: the 16-byte chunks past K are loaded from an out-of-range offset = zeros).  The segment
+  // of a k-step is read from the kernel arguments by a dynamic (uniform) index: a select chain over four preloaded descriptors
+  // became branches in the loop, and a branch there turns the counted vmcnt waits into vmcnt(0).
+  static_assert(offsetof(FwdJob<u16>, xseg) == offsetof(FwdJob<u16>, seg) + 2 * sizeof(Seg), "seg[] and xseg[] form one array of 4");
+  const Seg* segs = &J.seg[0];
+  int end0, end1, end2, end3;  // first k-step after each segment
+  end0 = (segs[0].K + kCellBK - 1) / kCellBK;
+  end1 = end0 + (segs[1].K + kCellBK - 1) / kCellBK;
+  end2 = end1 + (segs[2].K + kCellBK - 1) / kCellBK;
+  end3 = end2 + (segs[3].K + kCellBK - 1) / kCellBK;
+  const int dbg = jobs.glds;  // FHVAE_CELL_DBG (timing ablations; wrong results): 1 no K loop, 2 no epilogue, 4 no stores
+  const int nsteps = (dbg & 1) ? 0 : end3;
+  // image row of this lane's piece q: (wave * 4 + q) * 8 + (lane >> 3); logical chunk c8 lands in physical chunk lane & 7.
+  // Weight rows: image row j = wn' * 64 + g * 16 + i'  <->  row g * H + u0 + wn' * 16 + i' of W, i.e. piece q adds
+  // (q >> 1) * H + (q & 1) * 8 rows to piece 0's
+  const unsigned c8 = (unsigned)((lane & 7) ^ (lane >> 3));
+  const unsigned rowa0 = (unsigned)(wave * 32 + (lane >> 3));
+  const unsigned rowb0 = (unsigned)((wave & 1) * 2 * H + u0 + (wave >> 1) * 16 + (lane >> 3));
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -138,62 +164,107 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
     for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto issue = [&](char* stg, int ks) {
-    const bool s1 = ks >= sg.n0;
-    const unsigned kb = ks < sg.n ? (unsigned)((s1 ? ks - sg.n0 : ks) * (kCellBK * 2)) : kCellOob;
-    const __amdgpu_buffer_rsrc_t ra = s1 ? sg.a[1] : sg.a[0], rb = s1 ? sg.b[1] : sg.b[0];
+    int s = (ks >= end0) + (ks >= end1) + (ks >= end2);  // uniform
+    int start = ks >= end0 ? end0 : 0;
+    start = ks >= end1 ? end1 : start;
+    start = ks >= end2 ? end2 : start;
+    const int kl = ks - start;
+    const Seg& S = segs[s];
+    const unsigned la = (unsigned)(S.lda * 2), lb = (unsigned)(S.ldb * 2);
+    const __amdgpu_buffer_rsrc_t a = __builtin_amdgcn_make_buffer_rsrc((u16*)S.A + (int64_t)m0 * S.lda, 0, (int)(BM * la), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b = __builtin_amdgcn_make_buffer_rsrc((u16*)S.B, 0, (int)(4 * H * lb), 0x00020000);
+    // past the segment's K (or past the last step): bit 30 set = beyond num_records, the load returns zeros.  Plain ALU on
+    // purpose: selects here came back as exec-masked branches inside the loop
+    const int segK = S.K;
+    const unsigned oob = (unsigned)((int)(ks >= nsteps) | (int)(kl * kCellBK + (int)c8 * 8 >= segK)) << 30;
+    const unsigned kb = ((unsigned)(kl * (kCellBK * 2)) + c8 * 16u) | oob;
     unsigned xa[4], xb[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xa[q] = s1 ? va[1][q] : va[0][q], xb[q] = s1 ? vb[1][q] : vb[0][q];
-    cell_issue<4>(stg, ra, xa, kb, wave);
-    cell_issue<4>(stg + BM * 128, rb, xb, kb, wave);
+    for (int q = 0; q < 4; ++q) {
+      xa[q] = (rowa0 + (unsigned)(q * 8)) * la + kb;
+      xb[q] = (rowb0 + (unsigned)((q >> 1) * H + (q & 1) * 8)) * lb + kb;
+    }
+    cell_issue<4>(stg, a, xa, 0u, wave);
+    cell_issue<4>(stg + BM * 128, b, xb, 0u, wave);
   };
-  cell_mainloop<BM, RB, NS>(acc, sg.n, issue, st0, st1, st2, st3);
+  cell_mainloop<BM, RB, NS>(acc, nsteps, issue, st0, st1, st2, st3);
+  if (dbg & 2) {
+    if (acc[0][0][0] == 123.456f) J.c_out[0] = 0.f;
+    return;
+  }
 
-  // element offsets as 32-bit unsigned from uniform bases (64-bit per-element address arithmetic tripled the epilogue's VALU work)
-  const unsigned unit = u0 + wn * 16 + i;
+  // Epilogue through LDS: the accumulators (one lane = i,f,g,o of a (row, unit): 16 lanes x 4 B runs) go to an f32 image
+  // X[row][gate][32 units] (512 B per row; rows 0..63 in st0, 64..127 in st1), then every lane takes (row, 8 consecutive
+  // units) items: 16-byte global loads / stores, whole 64- / 128-byte runs per row (the per-lane form issued 12 two- and
+  // four-byte accesses per element).  16-byte slot s of a row sits at s ^ swz(row): conflict-free for the 4-byte writes
+  // (the four 4-row groups of a wave land on the four 64-byte quarters) and for the 16-byte reads.
+  auto swz = [](int row) { return (row & 1) ^ (((row >> 2) & 1) << 2) ^ ((((row >> 1) ^ (row >> 3)) & 1) << 3); };
   const unsigned uH = (unsigned)H;
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  if (J.bias_a) {
+  {
+    const unsigned unit = u0 + wn * 16 + i;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (J.bias_a) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bsum[g] = J.bias_a[g * uH + unit] + J.bias_b[g * uH + unit];
+      for (int g = 0; g < 4; ++g) bsum[g] = J.bias_a[g * uH + unit] + J.bias_b[g * uH + unit];
+    }
+    __syncthreads();  // every wave has read its last stage
+    char* xw = wm ? st1 : st0;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = tm * 16 + gq * 4 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int slot = g * 8 + wn * 4 + (i >> 2);
+          *(cell_lds_f)(xw + lr * 512 + ((slot ^ swz(lr)) << 4) + (i & 3) * 4) = acc[tm][g][r] + bsum[g];
+        }
+      }
+    __syncthreads();
   }
   const bool has_pre = J.pre != nullptr, has_cp = J.c_prev != nullptr;
   const float* prep = has_pre ? J.pre : J.c_out;  // stand-ins keep the loads unconditional (masked below)
-  const unsigned pld = has_pre ? (unsigned)J.pre_ld : 0u;
+  const unsigned pld = has_pre ? (unsigned)J.pre_ld : uH;
   const float* cprev = has_cp ? J.c_prev : J.c_out;
-  const unsigned row0 = m0 + wm * 64 + gq * 4;
+  const int lr = threadIdx.x >> 2, chunk = threadIdx.x & 3;
+  const unsigned u = u0 + chunk * 8;
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    float pa[4][4], cp[4];
+  for (int k = 0; k < 2; ++k) {
+    const char* xr = (k ? st1 : st0) + lr * 512;
+    const unsigned row = m0 + k * 64 + lr;
+    float x[4][8], pa[4][8], cp[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned row = row0 + tm * 16 + r;
+    for (int g = 0; g < 4; ++g) {
+      ld8(prep + row * pld + (has_pre ? g * uH + u : 0u), pa[g]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) pa[r][g] = prep[row * pld + (has_pre ? g * uH + unit : 0u)];
-      cp[r] = cprev[row * uH + unit];
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x4v v = *(cell_lds_f4)(xr + (((g * 8 + chunk * 2 + hh) ^ swz(lr)) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[g][hh * 4 + e] = v[e];
+      }
     }
+    ld8(cprev + row * uH + u, cp);
+    float ig[8], fg[8], gg[8], og[8], c[8], h[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned row = row0 + tm * 16 + r;
-      float x[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) x[g] = acc[tm][g][r] + (has_pre ? pa[r][g] : 0.f) + bsum[g];
-      const float ig = sigmoidf_(x[0]), fg = sigmoidf_(x[1]);
-      const float gg = tanhf_(x[2]), og = sigmoidf_(x[3]);
-      const float c = __builtin_fmaf(fg, has_cp ? cp[r] : 0.f, ig * gg);
-      const float h = og * tanhf_(c);
-      const unsigned o = row * uH + unit;
-      J.c_out[o] = c;
-      J.h_out[o] = f2bf(h);
-      if (J.h_out_f32) J.h_out_f32[o] = h;
-      u16* go = J.gates_out;
-      const unsigned og0 = row * 4u * uH + unit;
-      go[og0] = f2bf(ig);
-      go[og0 + uH] = f2bf(fg);
-      go[og0 + 2 * uH] = f2bf(gg);
-      go[og0 + 3 * uH] = f2bf(og);
-      if (J.hn_out) J.hn_out[row * (unsigned)J.hn_ld + unit] = h;
+    for (int e = 0; e < 8; ++e) {
+      ig[e] = sigmoidf_(x[0][e] + (has_pre ? pa[0][e] : 0.f));
+      fg[e] = sigmoidf_(x[1][e] + (has_pre ? pa[1][e] : 0.f));
+      gg[e] = tanhf_(x[2][e] + (has_pre ? pa[2][e] : 0.f));
+      og[e] = sigmoidf_(x[3][e] + (has_pre ? pa[3][e] : 0.f));
+      c[e] = __builtin_fmaf(fg[e], has_cp ? cp[e] : 0.f, ig[e] * gg[e]);
+      h[e] = og[e] * tanhf_(c[e]);
     }
+    const unsigned o = row * uH + u;
+    if ((dbg & 4) && c[0] != 123.456f) continue;
+    st8(J.c_out + o, c);
+    st8_bf(J.h_out + o, h);
+    if (J.h_out_f32) st8(J.h_out_f32 + o, h);
+    u16* go = J.gates_out + row * 4u * uH + u;
+    st8_bf(go, ig);
+    st8_bf(go + uH, fg);
+    st8_bf(go + 2 * uH, gg);
+    st8_bf(go + 3 * uH, og);
+    if (J.hn_out) st8(J.hn_out + row * (unsigned)J.hn_ld + u, h);
   }
 }
 
@@ -236,6 +307,8 @@ __global__ __launch_bounds__(kCellThreads, NS <= 3 ? 2 : 1) void cell_bwd_kernel
   }
   sg.n0 = J.seg[0].K / kCellBK;
   sg.n = sg.n0 + J.seg[1].K / kCellBK;
+  const int dbg = jobs.glds;
+  if (dbg & 1) sg.n = sg.n0 = 0;
 
   f32x4 acc[4][2];
 #pragma unroll
@@ -256,10 +329,31 @@ __global__ __launch_bounds__(kCellThreads, NS <= 3 ? 2 : 1) void cell_bwd_kernel
     cell_issue<2>(stg + BM * 128, rb, xb, kb, wave);
   };
   cell_mainloop<BM, BN, NS>(acc, sg.n, issue, st0, st1, st2, st3);
+  if (dbg & 2) {
+    if (acc[0][0][0] == 123.456f) J.dc[0] = 0.f;
+    return;
+  }
 
-  // Branch-free epilogue: an absent optional input is read from a valid stand-in (c_cur) and masked by a uniform select --
-  // with uniform branches per optional pointer the unrolled epilogue became a CFG of hundreds of blocks and spilled 270 VGPRs.
-  // Element offsets are 32-bit unsigned from uniform bases.
+  // Epilogue through LDS (see the forward cell): dh -> X[row][64 units] f32 (256 B per row; rows 0..63 in st0, 64..127 in
+  // st1), slot s of a row at s ^ swz(row); then (row, 8 units) items per lane with 16-byte global accesses.  Absent optional
+  // inputs are read from a valid stand-in (c_cur) and masked by a uniform select: no branches in the unrolled body.
+  auto swz = [](int row) { return (((row >> 2) & 3) << 2) ^ ((row >> 1) & 1); };
+  __syncthreads();
+  {
+    char* xw = wm ? st1 : st0;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = tm * 16 + gq * 4 + r;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          const int slot = wn * 8 + tn * 4 + (i >> 2);
+          *(cell_lds_f)(xw + lr * 256 + ((slot ^ swz(lr)) << 4) + (i & 3) * 4) = acc[tm][tn][r];
+        }
+      }
+  }
+  __syncthreads();
   const bool has_cp = J.c_prev != nullptr, has_e1 = J.ext != nullptr, has_e2 = J.ext2 != nullptr, first = J.first != 0;
   const unsigned uH = (unsigned)H;
   const float* cprev = has_cp ? J.c_prev : J.c_cur;
@@ -267,59 +361,70 @@ __global__ __launch_bounds__(kCellThreads, NS <= 3 ? 2 : 1) void cell_bwd_kernel
   const unsigned e1ld = has_e1 ? (unsigned)J.ext_ld : uH;
   const float* e2p = has_e2 ? J.ext2 : J.c_cur;
   const unsigned e2ld = has_e2 ? (unsigned)J.ext2_ld : uH;
-  const unsigned row0 = m0 + wm * 64 + gq * 4;
+  const int chunk = threadIdx.x & 7;
+  const unsigned u = n0 + chunk * 8;
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const unsigned unit = n0 + wn * 32 + tn * 16 + i;
+  for (int k = 0; k < 4; ++k) {
+    const int lr = (threadIdx.x >> 3) + 32 * (k & 1);
+    const char* xr = ((k >> 1) ? st1 : st0) + lr * 256;
+    const unsigned row = m0 + (k >> 1) * 64 + lr;
+    const unsigned o = row * uH + u, o4 = row * 4u * uH + u;
+    float dh[8], ig[8], fg[8], gg[8], og[8], cp[8], cc[8], dcin[8], e1[8], e2[8];
+    unpack_bf8(*(const u32x4v*)(J.gates + o4), ig);
+    unpack_bf8(*(const u32x4v*)(J.gates + o4 + uH), fg);
+    unpack_bf8(*(const u32x4v*)(J.gates + o4 + 2 * uH), gg);
+    unpack_bf8(*(const u32x4v*)(J.gates + o4 + 3 * uH), og);
+    ld8(cprev + o, cp);
+    ld8(J.c_cur + o, cc);
+    ld8(J.dc + o, dcin);
+    ld8(e1p + row * e1ld + u, e1);
+    ld8(e2p + row * e2ld + u, e2);
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-      float ig[4], fg[4], gg[4], og[4], cp[4], cc[4], dcin[4], e1[4], e2[4], dp[4][4];
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x4v v = *(cell_lds_f4)(xr + (((chunk * 2 + hh) ^ swz(lr)) << 4));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned row = row0 + tm * 16 + r;
-        const unsigned o = row * uH + unit, o4 = row * 4u * uH + unit;
-        ig[r] = bf2f(J.gates[o4]), fg[r] = bf2f(J.gates[o4 + uH]), gg[r] = bf2f(J.gates[o4 + 2 * uH]), og[r] = bf2f(J.gates[o4 + 3 * uH]);
-        cp[r] = cprev[o];
-        cc[r] = J.c_cur[o];
-        dcin[r] = J.dc[o];
-        e1[r] = e1p[row * e1ld + unit];
-        e2[r] = e2p[row * e2ld + unit];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned row = row0 + tm * 16 + r;
-        const unsigned o = row * uH + unit, o4 = row * 4u * uH + unit;
-        // same order of operations as lstm_bwd_step_kernel (lstm.hip): ext, then ext2
-        float dh = acc[tm][tn][r];
-        dh += has_e1 ? e1[r] : 0.f;
-        dh += has_e2 ? e2[r] : 0.f;
-        const float cpv = has_cp ? cp[r] : 0.f;
-        const float tc = tanhf_(cc[r]);
-        float dc = dh * og[r] * (1.f - tc * tc);
-        dc += first ? 0.f : dcin[r];
-        const float d_o = dh * tc;
-        const float d_i = dc * gg[r], d_f = dc * cpv, d_g = dc * ig[r];
-        J.dc[o] = dc * fg[r];
-        dp[r][0] = d_i * ig[r] * (1.f - ig[r]);
-        dp[r][1] = d_f * fg[r] * (1.f - fg[r]);
-        dp[r][2] = d_g * (1.f - gg[r] * gg[r]);
-        dp[r][3] = d_o * og[r] * (1.f - og[r]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) J.dg_out[o4 + g * uH] = f2bf(dp[r][g]);
-      }
-      if (J.dgsum) {
-        float old[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) old[r][g] = J.dgsum[(row0 + tm * 16 + r) * 4u * uH + g * uH + unit];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) J.dgsum[(row0 + tm * 16 + r) * 4u * uH + g * uH + unit] = (first ? 0.f : old[r][g]) + dp[r][g];
-      }
+      for (int e = 0; e < 4; ++e) dh[hh * 4 + e] = v[e];
     }
+    float dcn[8], dp[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // same order of operations as lstm_bwd_step_kernel (lstm.hip): ext, then ext2
+      float d = dh[e];
+      d += has_e1 ? e1[e] : 0.f;
+      d += has_e2 ? e2[e] : 0.f;
+      const float cpv = has_cp ? cp[e] : 0.f;
+      const float tc = tanhf_(cc[e]);
+      float dc = d * og[e] * (1.f - tc * tc);
+      dc += first ? 0.f : dcin[e];
+      const float d_o = d * tc;
+      const float d_i = dc * gg[e], d_f = dc * cpv, d_g = dc * ig[e];
+      dcn[e] = dc * fg[e];
+      dp[0][e] = d_i * ig[e] * (1.f - ig[e]);
+      dp[1][e] = d_f * fg[e] * (1.f - fg[e]);
+      dp[2][e] = d_g * (1.f - gg[e] * gg[e]);
+      dp[3][e] = d_o * og[e] * (1.f - og[e]);
+    }
+    if ((dbg & 4) && dcn[0] != 123.456f) continue;
+    st8(J.dc + o, dcn);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) st8_bf(J.dg_out + o4 + g * uH, dp[g]);
   }
+}
+
+// sum over t of the saved bf16 gate gradients of layer 0 -> f32 [B,4H]: what the time-constant input's gradients contract with
+// (the generic cells keep this sum as a read-modify-write of 32 MB per step; one pass over the 168 MB of dgates is cheaper)
+__global__ __launch_bounds__(256) void cell_dgsum_kernel(const u16* __restrict__ dg, float* __restrict__ out, int T, int64_t n) {
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (e >= n) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int t = 0; t < T; ++t) {
+    float v[8];
+    unpack_bf8(*(const u32x4v*)(dg + (int64_t)t * n + e), v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+  st8(out + e, acc);
 }
 
 template __global__ void cell_fwd_kernel<2>(FwdJobs<u16>);
@@ -328,9 +433,11 @@ template __global__ void cell_bwd_kernel<2>(BwdJobs<u16>);
 template __global__ void cell_bwd_kernel<3>(BwdJobs<u16>);
 template __global__ void cell_bwd_kernel<4>(BwdJobs<u16>);
 
-static bool cell_seg_ok(const Seg& s, int64_t rows_a, int64_t rows_b) {
+static bool cell_misaligned(const void* p) { return (((uintptr_t)p) & 15) != 0; }
+
+static bool cell_seg_ok(const Seg& s, int64_t rows_a, int64_t rows_b, int kmult) {
   if (s.K == 0) return true;
-  if (!s.a_kc || !s.b_kc || s.a_rmod || (s.K % kCellBK) || (s.lda % 8) || (s.ldb % 8)) return false;
+  if (!s.a_kc || !s.b_kc || s.a_rmod || (s.K % kmult) || (s.lda % 8) || (s.ldb % 8)) return false;
   if ((((uintptr_t)s.A) | ((uintptr_t)s.B)) & 15) return false;
   // 32-bit buffer offsets below kCellOob
   return rows_a * s.lda * 2 < (int64_t)kCellOob && rows_b * s.ldb * 2 < (int64_t)kCellOob;
@@ -341,10 +448,17 @@ bool cell_fwd_big_ok(const FwdJobs<u16>& jobs, int nj) {
   for (int j = 0; j < nj; ++j) {
     const FwdJob<u16>& J = jobs.job[j];
     if ((J.pre && J.pre_ld * jobs.B * 4 >= (1LL << 31)) || (J.hn_out && J.hn_ld * jobs.B * 4 >= (1LL << 31))) return false;
+    // 16-byte epilogue accesses
+    if ((J.pre && (J.pre_ld % 4)) || (J.hn_out && (J.hn_ld % 4))) return false;
+    if (cell_misaligned(J.pre) || cell_misaligned(J.c_prev) || cell_misaligned(J.c_out) || cell_misaligned(J.h_out) ||
+        cell_misaligned(J.h_out_f32) || cell_misaligned(J.gates_out) || cell_misaligned(J.hn_out))
+      return false;
   }
   for (int j = 0; j < nj; ++j)
-    for (int s = 0; s < 2; ++s)
-      if (!cell_seg_ok(jobs.job[j].seg[s], 128, 4 * (int64_t)jobs.H)) return false;
+    for (int s = 0; s < 2; ++s) {
+      if (!cell_seg_ok(jobs.job[j].seg[s], 128, 4 * (int64_t)jobs.H, kCellBK)) return false;
+      if (!cell_seg_ok(jobs.job[j].xseg[s], 128, 4 * (int64_t)jobs.H, 8)) return false;
+    }
   return true;
 }
 
@@ -353,32 +467,48 @@ bool cell_bwd_big_ok(const BwdJobs<u16>& jobs, int nj) {
   for (int j = 0; j < nj; ++j) {
     const BwdJob<u16>& J = jobs.job[j];
     if ((J.ext && J.ext_ld * jobs.B * 4 >= (1LL << 31)) || (J.ext2 && J.ext2_ld * jobs.B * 4 >= (1LL << 31))) return false;
+    if ((J.ext && (J.ext_ld % 4)) || (J.ext2 && (J.ext2_ld % 4))) return false;
+    if (cell_misaligned(J.ext) || cell_misaligned(J.ext2) || cell_misaligned(J.gates) || cell_misaligned(J.c_prev) ||
+        cell_misaligned(J.c_cur) || cell_misaligned(J.dc) || cell_misaligned(J.dg_out))
+      return false;
   }
   for (int j = 0; j < nj; ++j)
     for (int s = 0; s < 2; ++s)
-      if (!cell_seg_ok(jobs.job[j].seg[s], 128, 64)) return false;
+      if (!cell_seg_ok(jobs.job[j].seg[s], 128, 64, kCellBK)) return false;
   return true;
 }
 
 int launch_cell_fwd_big(const FwdJobs<u16>& jobs, int nj, hipStream_t st) {
   static const int ns = getenv("FHVAE_CELL_FWD_NS") ? atoi(getenv("FHVAE_CELL_FWD_NS")) : 2;
+  static const int dbg = getenv("FHVAE_CELL_DBG") ? atoi(getenv("FHVAE_CELL_DBG")) : 0;
+  FwdJobs<u16> jd = jobs;
+  jd.glds = dbg;
   const dim3 grid((unsigned)(jobs.B / 128), (unsigned)(jobs.H / 32), (unsigned)nj), block(kCellThreads);
   if (ns == 3)
-    hipLaunchKernelGGL((cell_fwd_kernel<3>), grid, block, 0, st, jobs);
+    hipLaunchKernelGGL((cell_fwd_kernel<3>), grid, block, 0, st, jd);
   else
-    hipLaunchKernelGGL((cell_fwd_kernel<2>), grid, block, 0, st, jobs);
+    hipLaunchKernelGGL((cell_fwd_kernel<2>), grid, block, 0, st, jd);
   return fh_launch_status();
 }
 
 int launch_cell_bwd_big(const BwdJobs<u16>& jobs, int nj, hipStream_t st) {
   static const int ns = getenv("FHVAE_CELL_BWD_NS") ? atoi(getenv("FHVAE_CELL_BWD_NS")) : 3;
+  static const int dbg = getenv("FHVAE_CELL_DBG") ? atoi(getenv("FHVAE_CELL_DBG")) : 0;
+  BwdJobs<u16> jd = jobs;
+  jd.glds = dbg;
   const dim3 grid((unsigned)(jobs.B / 128), (unsigned)(jobs.H / 64), (unsigned)nj), block(kCellThreads);
   if (ns == 2)
-    hipLaunchKernelGGL((cell_bwd_kernel<2>), grid, block, 0, st, jobs);
+    hipLaunchKernelGGL((cell_bwd_kernel<2>), grid, block, 0, st, jd);
   else if (ns == 4)
-    hipLaunchKernelGGL((cell_bwd_kernel<4>), grid, block, 0, st, jobs);
+    hipLaunchKernelGGL((cell_bwd_kernel<4>), grid, block, 0, st, jd);
   else
-    hipLaunchKernelGGL((cell_bwd_kernel<3>), grid, block, 0, st, jobs);
+    hipLaunchKernelGGL((cell_bwd_kernel<3>), grid, block, 0, st, jd);
+  return fh_launch_status();
+}
+
+int launch_cell_dgsum(const u16* dg, float* out, int T, int64_t n, hipStream_t st) {
+  if ((n % 8) || cell_misaligned(dg) || cell_misaligned(out)) return FHVAE_ERR_ALIGN;
+  hipLaunchKernelGGL(cell_dgsum_kernel, dim3((unsigned)fh_cdiv(n / 8, 256)), dim3(256), 0, st, dg, out, T, n);
   return fh_launch_status();
 }
 
