@@ -501,13 +501,28 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
       return cluster_fwd(d, cw, st);
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    if (cell_big) {  // large-tile cells (lstm_cell.hip)
+      for (int64_t w = 0; w < T_ + L - 1; ++w) {
+        int nj = 0;
+        const FwdJobs<u16> jobs = fwd_jobs(d, op, w, true, nj);
+        double fl = 0;
+        for (int j = 0; j < nj; ++j)
+          fl += 2.0 * B * 4 * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K + jobs.job[j].xseg[0].K + jobs.job[j].xseg[1].K);
+        const int ts = trace_begin(st, kTraceFwdCell, fl);
+        const int e = launch_cell_fwd_big(jobs, nj, st);
+        trace_end(st, ts);
+        if (e) return e;
+      }
+      return FHVAE_OK;
+    }
+  }
   // ---- wavefront over (layer, time)
   for (int64_t w = 0; w < T_ + L - 1; ++w) {
     int nj = 0;
-    const FwdJobs<T> jobs = fwd_jobs(d, op, w, cell_big, nj);
+    const FwdJobs<T> jobs = fwd_jobs(d, op, w, false, nj);
     double fl = 0;
-    for (int j = 0; j < nj; ++j)
-      fl += 2.0 * B * 4 * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K + jobs.job[j].xseg[0].K + jobs.job[j].xseg[1].K);
+    for (int j = 0; j < nj; ++j) fl += 2.0 * B * 4 * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
     const int ts = trace_begin(st, kTraceFwdCell, fl);
     // large tiles (half the L2 -> LDS operand bytes per FLOP) only pay once they still give >= 2 workgroups per CU (see
     // gemm.hip): B >= 16384 at H = 256, B >= 2048 at H = 512 (configs[3]: 2048 workgroups of 64x64 pulled 14 TB/s from L2)
@@ -515,12 +530,7 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     // (measured at B = 2048, H = 512, bf16: 128x128 tiles 1.3-1.8 ms per net forward against 1.0-1.3 ms with 64x64: the
     //  heuristic stays "B >= 16384"; FHVAE_FWD_TILE overrides for experiments)
     const bool big_fwd = fwd_tile ? fwd_tile == 128 : B >= 16384;
-    if (cell_big) {
-      if constexpr (sizeof(T) == 2) {
-        const int e = launch_cell_fwd_big(jobs, nj, st);
-        if (e) return e;
-      }
-    } else if (big_fwd) {
+    if (big_fwd) {
       dim3 grid((unsigned)fh_cdiv(B, 128), (unsigned)fh_cdiv(H, 32), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 128, 128, 2, 2, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else if (B >= 1024) {
@@ -553,6 +563,64 @@ extern "C" int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream) {
   return lstm_fwd_impl<u16>(d, ops_bf16(d), st);
 }
 
+// the backward jobs of wavefront step w (layer l at time T-1-(w-(L-1-l)))
+template <typename T>
+static BwdJobs<T> bwd_jobs(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, int64_t w, int& nj) {
+  const fhvae_lstm_desc* d = &bd->f;
+  const int64_t B = d->B, T_ = d->T, Ic = d->Ic, H = d->H;
+  const int L = d->L;
+  constexpr bool kF32 = sizeof(T) == 4;
+  T* dg = (T*)bd->dgates;
+  BwdJobs<T> jobs = {};
+  jobs.B = (int)B;
+  jobs.H = (int)H;
+  jobs.glds = getenv("FHVAE_NO_GLDS") ? 0 : 1;
+  nj = 0;
+  // f32: the weights are read untransposed as KM operands; bf16: the transposed copies [H,4H] are KC operands.
+  for (int l = L - 1; l >= 0; --l) {
+    const int64_t u = w - (L - 1 - l);
+    if (u < 0 || u >= T_) continue;
+    const int64_t t = T_ - 1 - u;
+    BwdJob<T>& J = jobs.job[nj++];
+    const int64_t lt = (int64_t)l * T_ + t;
+    if (t < T_ - 1) {
+      const T* a = dg + (lt + 1) * B * 4 * H;
+      J.seg[0] = kF32 ? Seg{a, 4 * H, 1, op.w_hh[l], H, 0, (int)(4 * H), 0}
+                      : Seg{a, 4 * H, 1, op.w_hh_t[l], 4 * H, 1, (int)(4 * H), 0};
+    }
+    if (l < L - 1) {
+      const T* a = dg + ((int64_t)(l + 1) * T_ + t) * B * 4 * H;
+      J.seg[1] = kF32 ? Seg{a, 4 * H, 1, op.w_ih[l + 1], H, 0, (int)(4 * H), 0}
+                      : Seg{a, 4 * H, 1, op.w_ih_t[l + 1], 4 * H, 1, (int)(4 * H), 0};
+    }
+    if (l == L - 1 && bd->d_hs_top) {
+      J.ext = bd->d_hs_top + t * B * H;
+      J.ext_ld = H;
+    }
+    if (t == T_ - 1 && bd->d_hn) {
+      J.ext2 = bd->d_hn + (int64_t)l * H;
+      J.ext2_ld = (int64_t)L * H;
+    }
+    J.gates = (const T*)d->gates + lt * B * 4 * H;
+    J.c_prev = t > 0 ? d->cs + (lt - 1) * B * H : nullptr;
+    J.c_cur = d->cs + lt * B * H;
+    J.dc = bd->dc + (int64_t)l * B * H;
+    J.first = t == T_ - 1;
+    J.dg_out = dg + lt * B * 4 * H;
+    J.dgsum = (l == 0 && Ic > 0) ? bd->dgsum : nullptr;
+  }
+  return jobs;
+}
+
+static bool cell_bwd_plan_ok(const fhvae_lstm_bwd_desc* bd, const Ops<u16>& op) {
+  for (int64_t w = 0; w < bd->f.T + bd->f.L - 1; ++w) {
+    int nj = 0;
+    const BwdJobs<u16> jobs = bwd_jobs<u16>(bd, op, w, nj);
+    if (!cell_bwd_big_ok(jobs, nj)) return false;
+  }
+  return true;
+}
+
 template <typename T>
 static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;
@@ -566,48 +634,27 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
       cw.xch = (u16*)d->lp + lp_layout(d).xch;
       return cluster_bwd(bd, cw, st);
     }
-  }
-  T* dg = (T*)bd->dgates;
-  bool big_any = false, big_all = true;
-  // f32: the weights are read untransposed as KM operands; bf16: the transposed copies [H,4H] are KC operands.
-  for (int64_t w = 0; w < T_ + L - 1; ++w) {
-    BwdJobs<T> jobs = {};
-    jobs.B = (int)B;
-    jobs.H = (int)H;
-    jobs.glds = getenv("FHVAE_NO_GLDS") ? 0 : 1;
-    int nj = 0;
-    for (int l = L - 1; l >= 0; --l) {
-      const int64_t u = w - (L - 1 - l);
-      if (u < 0 || u >= T_) continue;
-      const int64_t t = T_ - 1 - u;
-      BwdJob<T>& J = jobs.job[nj++];
-      const int64_t lt = (int64_t)l * T_ + t;
-      if (t < T_ - 1) {
-        const T* a = dg + (lt + 1) * B * 4 * H;
-        J.seg[0] = kF32 ? Seg{a, 4 * H, 1, op.w_hh[l], H, 0, (int)(4 * H), 0}
-                        : Seg{a, 4 * H, 1, op.w_hh_t[l], 4 * H, 1, (int)(4 * H), 0};
+    if (big_cells(B, H) && cell_bwd_plan_ok(bd, op)) {
+      // large-tile cells (lstm_cell.hip); they leave the time sum of layer 0's gate gradients to one pass over the saved
+      // bf16 dgates.  (Tried: the batch rows as 2 / 4 independent launch chains on side streams, so that one chain's
+      // HBM-bound epilogue would run beside the other's contraction: 348 k / 312 k segments/s against 361 k for one chain.)
+      for (int64_t w = 0; w < T_ + L - 1; ++w) {
+        int nj = 0;
+        const BwdJobs<u16> jobs = bwd_jobs<u16>(bd, op, w, nj);
+        double fl = 0;
+        for (int j = 0; j < nj; ++j) fl += 2.0 * B * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
+        const int ts = trace_begin(st, kTraceBwdCell, fl);
+        const int e = launch_cell_bwd_big(jobs, nj, st);
+        trace_end(st, ts);
+        if (e) return e;
       }
-      if (l < L - 1) {
-        const T* a = dg + ((int64_t)(l + 1) * T_ + t) * B * 4 * H;
-        J.seg[1] = kF32 ? Seg{a, 4 * H, 1, op.w_ih[l + 1], H, 0, (int)(4 * H), 0}
-                        : Seg{a, 4 * H, 1, op.w_ih_t[l + 1], 4 * H, 1, (int)(4 * H), 0};
-      }
-      if (l == L - 1 && bd->d_hs_top) {
-        J.ext = bd->d_hs_top + t * B * H;
-        J.ext_ld = H;
-      }
-      if (t == T_ - 1 && bd->d_hn) {
-        J.ext2 = bd->d_hn + (int64_t)l * H;
-        J.ext2_ld = (int64_t)L * H;
-      }
-      J.gates = (const T*)d->gates + lt * B * 4 * H;
-      J.c_prev = t > 0 ? d->cs + (lt - 1) * B * H : nullptr;
-      J.c_cur = d->cs + lt * B * H;
-      J.dc = bd->dc + (int64_t)l * B * H;
-      J.first = t == T_ - 1;
-      J.dg_out = dg + lt * B * 4 * H;
-      J.dgsum = (l == 0 && Ic > 0) ? bd->dgsum : nullptr;
+      if (Ic > 0) return launch_cell_dgsum((const u16*)bd->dgates, bd->dgsum, (int)T_, B * 4 * H, st);
+      return FHVAE_OK;
     }
+  }
+  for (int64_t w = 0; w < T_ + L - 1; ++w) {
+    int nj = 0;
+    const BwdJobs<T> jobs = bwd_jobs<T>(bd, op, w, nj);
     double fl = 0;
     for (int j = 0; j < nj; ++j) fl += 2.0 * B * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
     const int ts = trace_begin(st, kTraceBwdCell, fl);
@@ -616,14 +663,7 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     static const int bwd_tile = getenv("FHVAE_BWD_TILE") ? atoi(getenv("FHVAE_BWD_TILE")) : 0;
     // (measured at B = 2048, H = 512, bf16: 64x64 tiles 2.4 ms per net backward, 32x32 2.2-2.3 ms: no gain from larger tiles)
     const int bt = bwd_tile ? bwd_tile : (B >= 16384 ? 128 : 32);
-    bool cell_big = false;
-    if constexpr (!kF32) cell_big = big_cells(B, H) && cell_bwd_big_ok(jobs, nj);
-    if (cell_big) {
-      if constexpr (!kF32) {
-        const int e = launch_cell_bwd_big(jobs, nj, st);
-        if (e) return e;
-      }
-    } else if (bt == 128) {
+    if (bt == 128) {
       dim3 grid((unsigned)fh_cdiv(B, 128), (unsigned)fh_cdiv(H, 64), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 128, 64, 4, 1, 16>), grid, dim3(kThreads), 0, st, jobs);
     } else if (bt == 64) {
@@ -639,15 +679,6 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     trace_end(st, ts);
     int e = fh_launch_status();
     if (e) return e;
-    big_any = big_any || cell_big;
-    big_all = big_all && cell_big;
-  }
-  if constexpr (!kF32) {
-    // the large-tile cells leave the time sum of layer 0's gate gradients to one pass over the saved bf16 dgates
-    if (big_any && Ic > 0) {
-      if (!big_all) return FHVAE_ERR_SHAPE;  // (the predicate is the same for every step of a sequence)
-      return launch_cell_dgsum((const u16*)dg, bd->dgsum, (int)T_, B * 4 * H, st);
-    }
   }
   return FHVAE_OK;
 }

@@ -269,11 +269,11 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward cell: 128 rows x 64 units
+// backward cell: BM (128 or 64) rows x 64 units
 // ---------------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(kCellThreads, NS <= 3 ? 2 : 1) void cell_bwd_kernel(BwdJobs<u16> jobs) {
-  constexpr int BM = 128, BN = 64;
+template <int BM, int NS>
+__global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2 : 1) void cell_bwd_kernel(BwdJobs<u16> jobs) {
+  constexpr int BN = 64, TM = BM / 32, NIA = BM / 32;
   constexpr int STAGE = (BM + BN) * 128;
   __shared__ __attribute__((aligned(1024))) char st0[STAGE];
   __shared__ __attribute__((aligned(1024))) char st1[STAGE];
@@ -287,16 +287,16 @@ __global__ __launch_bounds__(kCellThreads, NS <= 3 ? 2 : 1) void cell_bwd_kernel
   const int i = lane & 15, gq = lane >> 4;
 
   CellSegs sg;
-  unsigned va[2][4], vb[2][2];
+  unsigned va[2][NIA], vb[2][2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const Seg& S = J.seg[s];
     const bool on = S.K > 0;
-    sg.a[s] = cell_rsrc(on ? (const u16*)S.A + (int64_t)m0 * S.lda : nullptr, (int64_t)BM * S.lda * 2);
-    sg.b[s] = cell_rsrc(on ? (const u16*)S.B + (int64_t)n0 * S.ldb : nullptr, (int64_t)BN * S.ldb * 2);
+    sg.a[s] = cell_rsrc(on ? (const u16*)S.A + (int64_t)((jobs.glds & 8) ? 0 : m0) * S.lda : nullptr, (int64_t)BM * S.lda * 2);
+    sg.b[s] = cell_rsrc(on ? (const u16*)S.B + (int64_t)((jobs.glds & 16) ? 0 : n0) * S.ldb : nullptr, (int64_t)BN * S.ldb * 2);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = (wave * 4 + q) * 8 + (lane >> 3);
+    for (int q = 0; q < NIA; ++q) {
+      const int row = (wave * NIA + q) * 8 + (lane >> 3);
       va[s][q] = (unsigned)row * (unsigned)(S.lda * 2) + (unsigned)((lane & 7) ^ (row & 7)) * 16u;
     }
 #pragma unroll
@@ -310,9 +310,9 @@ __global__ __launch_bounds__(kCellThreads, NS <= 3 ? 2 : 1) void cell_bwd_kernel
   const int dbg = jobs.glds;
   if (dbg & 1) sg.n = sg.n0 = 0;
 
-  f32x4 acc[4][2];
+  f32x4 acc[TM][2];
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -320,12 +320,12 @@ __global__ __launch_bounds__(kCellThreads, NS <= 3 ? 2 : 1) void cell_bwd_kernel
     const bool s1 = ks >= sg.n0;
     const unsigned kb = ks < sg.n ? (unsigned)((s1 ? ks - sg.n0 : ks) * (kCellBK * 2)) : kCellOob;
     const __amdgpu_buffer_rsrc_t ra = s1 ? sg.a[1] : sg.a[0], rb = s1 ? sg.b[1] : sg.b[0];
-    unsigned xa[4], xb[2];
+    unsigned xa[NIA], xb[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xa[q] = s1 ? va[1][q] : va[0][q];
+    for (int q = 0; q < NIA; ++q) xa[q] = s1 ? va[1][q] : va[0][q];
 #pragma unroll
     for (int q = 0; q < 2; ++q) xb[q] = s1 ? vb[1][q] : vb[0][q];
-    cell_issue<4>(stg, ra, xa, kb, wave);
+    cell_issue<NIA>(stg, ra, xa, kb, wave);
     cell_issue<2>(stg + BM * 128, rb, xb, kb, wave);
   };
   cell_mainloop<BM, BN, NS>(acc, sg.n, issue, st0, st1, st2, st3);
@@ -334,15 +334,15 @@ __global__ __launch_bounds__(kCellThreads, NS <= 3 ? 2 : 1) void cell_bwd_kernel
     return;
   }
 
-  // Epilogue through LDS (see the forward cell): dh -> X[row][64 units] f32 (256 B per row; rows 0..63 in st0, 64..127 in
-  // st1), slot s of a row at s ^ swz(row); then (row, 8 units) items per lane with 16-byte global accesses.  Absent optional
+  // Epilogue through LDS (see the forward cell): dh -> X[row][64 units] f32 (256 B per row; the rows of wave row wm in
+  // st<wm>), slot s of a row at s ^ swz(row); then (row, 8 units) items per lane with 16-byte global accesses.  Absent optional
   // inputs are read from a valid stand-in (c_cur) and masked by a uniform select: no branches in the unrolled body.
   auto swz = [](int row) { return (((row >> 2) & 3) << 2) ^ ((row >> 1) & 1); };
   __syncthreads();
   {
     char* xw = wm ? st1 : st0;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int lr = tm * 16 + gq * 4 + r;
@@ -364,10 +364,10 @@ __global__ __launch_bounds__(kCellThreads, NS <= 3 ? 2 : 1) void cell_bwd_kernel
   const int chunk = threadIdx.x & 7;
   const unsigned u = n0 + chunk * 8;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int lr = (threadIdx.x >> 3) + 32 * (k & 1);
-    const char* xr = ((k >> 1) ? st1 : st0) + lr * 256;
-    const unsigned row = m0 + (k >> 1) * 64 + lr;
+  for (int k = 0; k < BM / 32; ++k) {  // 32 rows x 8 chunks per pass
+    const int wmk = k / (BM / 64), lr = (threadIdx.x >> 3) + 32 * (k % (BM / 64));
+    const char* xr = (wmk ? st1 : st0) + lr * 256;
+    const unsigned row = m0 + wmk * (BM / 2) + lr;
     const unsigned o = row * uH + u, o4 = row * 4u * uH + u;
     float dh[8], ig[8], fg[8], gg[8], og[8], cp[8], cc[8], dcin[8], e1[8], e2[8];
     unpack_bf8(*(const u32x4v*)(J.gates + o4), ig);
@@ -429,9 +429,10 @@ __global__ __launch_bounds__(256) void cell_dgsum_kernel(const u16* __restrict__
 
 template __global__ void cell_fwd_kernel<2>(FwdJobs<u16>);
 template __global__ void cell_fwd_kernel<3>(FwdJobs<u16>);
-template __global__ void cell_bwd_kernel<2>(BwdJobs<u16>);
-template __global__ void cell_bwd_kernel<3>(BwdJobs<u16>);
-template __global__ void cell_bwd_kernel<4>(BwdJobs<u16>);
+template __global__ void cell_bwd_kernel<128, 3>(BwdJobs<u16>);
+template __global__ void cell_bwd_kernel<128, 4>(BwdJobs<u16>);
+template __global__ void cell_bwd_kernel<64, 3>(BwdJobs<u16>);
+template __global__ void cell_bwd_kernel<64, 4>(BwdJobs<u16>);
 
 static bool cell_misaligned(const void* p) { return (((uintptr_t)p) & 15) != 0; }
 
@@ -492,17 +493,20 @@ int launch_cell_fwd_big(const FwdJobs<u16>& jobs, int nj, hipStream_t st) {
 }
 
 int launch_cell_bwd_big(const BwdJobs<u16>& jobs, int nj, hipStream_t st) {
-  static const int ns = getenv("FHVAE_CELL_BWD_NS") ? atoi(getenv("FHVAE_CELL_BWD_NS")) : 3;
+  static const int ns = getenv("FHVAE_CELL_BWD_NS") ? atoi(getenv("FHVAE_CELL_BWD_NS")) : 4;
+  static const int bm = getenv("FHVAE_CELL_BWD_BM") ? atoi(getenv("FHVAE_CELL_BWD_BM")) : 64;
   static const int dbg = getenv("FHVAE_CELL_DBG") ? atoi(getenv("FHVAE_CELL_DBG")) : 0;
   BwdJobs<u16> jd = jobs;
   jd.glds = dbg;
-  const dim3 grid((unsigned)(jobs.B / 128), (unsigned)(jobs.H / 64), (unsigned)nj), block(kCellThreads);
-  if (ns == 2)
-    hipLaunchKernelGGL((cell_bwd_kernel<2>), grid, block, 0, st, jd);
-  else if (ns == 4)
-    hipLaunchKernelGGL((cell_bwd_kernel<4>), grid, block, 0, st, jd);
+  const dim3 grid((unsigned)(jobs.B / (bm == 128 ? 128 : 64)), (unsigned)(jobs.H / 64), (unsigned)nj), block(kCellThreads);
+  if (bm == 128 && ns == 3)
+    hipLaunchKernelGGL((cell_bwd_kernel<128, 3>), grid, block, 0, st, jd);
+  else if (bm == 128)
+    hipLaunchKernelGGL((cell_bwd_kernel<128, 4>), grid, block, 0, st, jd);
+  else if (ns == 3)
+    hipLaunchKernelGGL((cell_bwd_kernel<64, 3>), grid, block, 0, st, jd);
   else
-    hipLaunchKernelGGL((cell_bwd_kernel<3>), grid, block, 0, st, jd);
+    hipLaunchKernelGGL((cell_bwd_kernel<64, 4>), grid, block, 0, st, jd);
   return fh_launch_status();
 }
 

@@ -89,7 +89,7 @@ def test_bench_shape_bf16_lstm_fwd_bwd_vs_torch_lstm(hb, I, Ic):
         assert rel < 1.5e-2, (n, rel)
 
 
-@pytest.mark.parametrize("B,T,I,Ic", [(256, 6, 80, 32), (256, 5, 80, 0), (384, 4, 0, 64)])
+@pytest.mark.parametrize("B,T,I,Ic", [(256, 6, 80, 32), (256, 5, 80, 0), (384, 4, 0, 64), (1024, 3, 80, 32)])
 def test_big_cells_h512_bf16_vs_torch_lstm_and_generic_cells(hb, monkeypatch, B, T, I, Ic):
     """The large-tile bf16 step cells (lstm_cell.hip; configs[3] at the bench batch) forced on at a batch the CPU oracle
     handles: against torch.nn.LSTM with the bf16 tolerances of the tests above, and against the generic step cells on the same
