@@ -16,6 +16,7 @@
 #include "gemm_launch.h"
 #include "lstm_cell.h"
 #include "lstm_cluster.h"
+#include "lstm_stream.h"
 #include "wgrad.h"
 #include <algorithm>
 #include <vector>
@@ -404,6 +405,14 @@ static bool big_cells(int64_t B, int64_t H) {
   return (B / 128) * (H / 64) >= 96;
 }
 
+static StreamWeights stream_weights(const Ops<u16>& op) {
+  StreamWeights w = {};
+  w.x = op.x, w.xc = op.xc;
+  for (int l = 0; l < FHVAE_MAX_LAYERS; ++l) w.w_ih[l] = op.w_ih[l], w.w_hh[l] = op.w_hh[l], w.w_ih_t[l] = op.w_ih_t[l], w.w_hh_t[l] = op.w_hh_t[l];
+  return w;
+}
+static StreamWeights stream_weights(const Ops<float>&) { return StreamWeights{}; }
+
 // the forward jobs of wavefront step w; `big`: for the large-tile cells, which multiply layer 0's input themselves (no `pre`)
 template <typename T>
 static FwdJobs<T> fwd_jobs(const fhvae_lstm_desc* d, const Ops<T>& op, int64_t w, bool big, int& nj) {
@@ -474,8 +483,11 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     xc_in = cluster && cluster_xc_in_kernel(d);
   }
   // large-tile step cells (lstm_cell.hip; all steps of the sequence or none): they multiply layer 0's input themselves
-  bool cell_big = false;
-  if constexpr (sizeof(T) == 2) cell_big = !cluster && big_cells(B, H) && cell_fwd_plan_ok(d, op);
+  bool cell_big = false, stream = false;
+  if constexpr (sizeof(T) == 2) {
+    stream = !cluster && big_cells(B, H) && stream_eligible(d);  // ... as one persistent launch (lstm_stream.hip)
+    cell_big = stream || (!cluster && big_cells(B, H) && cell_fwd_plan_ok(d, op));
+  }
   if (!cell_big && !(fold && Ic == 0) && !xc_in) {
     GemmParams p = {};
     int s = 0;
@@ -502,6 +514,7 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     }
   }
   if constexpr (sizeof(T) == 2) {
+    if (stream) return stream_fwd(d, stream_weights(op), st);
     if (cell_big) {  // large-tile cells (lstm_cell.hip)
       for (int64_t w = 0; w < T_ + L - 1; ++w) {
         int nj = 0;
@@ -633,6 +646,12 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
       for (int l = 0; l < L; ++l) cw.w_ih[l] = op.w_ih[l], cw.w_hh[l] = op.w_hh[l], cw.w_ih_t[l] = op.w_ih_t[l], cw.w_hh_t[l] = op.w_hh_t[l];
       cw.xch = (u16*)d->lp + lp_layout(d).xch;
       return cluster_bwd(bd, cw, st);
+    }
+    if (big_cells(B, H) && stream_eligible(d)) {  // the forward took the same form (same predicate)
+      const int e = stream_bwd(bd, stream_weights(op), st);
+      if (e) return e;
+      if (Ic > 0) return launch_cell_dgsum((const u16*)bd->dgates, bd->dgsum, (int)T_, B * 4 * H, st);
+      return FHVAE_OK;
     }
     if (big_cells(B, H) && cell_bwd_plan_ok(bd, op)) {
       // large-tile cells (lstm_cell.hip); they leave the time sum of layer 0's gate gradients to one pass over the saved

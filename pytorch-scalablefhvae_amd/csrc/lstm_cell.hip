@@ -10,108 +10,12 @@
 // [row][128 B] with the 16-byte chunk index XOR-ed by (row & 7) on the DMA source side and on the ds_read_b128 side
 // (conflict-free, guide T2).  Semantics of the cells: lstm.hip (torch.nn.LSTM gate order i,f,g,o; stands where the FC layers of
 // simple_fhvae.py:160-164, :186-190, :240-244 stand).
-#include "lstm_cell.h"
+#include "lstm_cell_dev.h"
 
 #include <cstddef>
 #include <cstdlib>
 
 namespace fh {
-
-constexpr int kCellThreads = 256;
-constexpr int kCellBK = 64;
-constexpr unsigned kCellOob = 0x40000000u;  // beyond every descriptor's num_records: the load returns zeros
-
-typedef void __attribute__((address_space(3))) * cell_lds_p;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t cell_rsrc(const void* p, int64_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
-}
-
-// one stage of one operand: NI wave-instructions of 1 KiB (8 image rows x 128 B) per wave
-template <int NI>
-__device__ __forceinline__ void cell_issue(char* img, __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[NI], unsigned kbytes, int wave) {
-#pragma unroll
-  for (int q = 0; q < NI; ++q)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cell_lds_p)(img + (wave * NI + q) * 1024), 16, voff[q] + kbytes, 0, 0, 0);
-}
-
-__device__ __forceinline__ bf16x8 cell_frag(const char* img, int off) {
-  typedef bf16x8 __attribute__((address_space(3))) * lp;
-  return *(lp)(img + off);
-}
-
-// The K loop shared by both cells.  RA / RB: image rows of the A (batch rows) and B (weight rows) operands; a wave owns
-// TM x TN 16x16 tiles at A rows wm * RA/2 ..., B rows wn * RB/2 ....  `issue(stage, ks)` starts the DMA of k-step ks (zeros
-// past the last one).  Step s: wait for this wave's pieces of stage s, barrier (all pieces landed; everybody is done with
-// stage s-1), refill stage s-1's buffer with step s+NS-1, multiply stage s.
-template <int RA, int RB, int NS, typename Issue>
-__device__ __forceinline__ void cell_mainloop(f32x4 (&acc)[RA / 32][RB / 32], int nsteps, Issue&& issue, char* s0, char* s1, char* s2, char* s3) {
-  constexpr int TM = RA / 32, TN = RB / 32;
-  constexpr int NLOAD = RA / 32 + RB / 32;
-  constexpr int ABYTES = RA * 128;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int i = lane & 15, gq = lane >> 4;
-  const int offa = (wm * (RA / 2) + i) * 128, offb = ABYTES + (wn * (RB / 2) + i) * 128;
-  int cj[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) cj[j] = ((j * 4 + gq) ^ (i & 7)) << 4;
-  char* bufs[4] = {s0, s1, s2, s3};
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(bufs[s], s);
-  auto step = [&](const char* cur, char* nxt, int ks_next) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NLOAD) : "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(nxt, ks_next);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bf16x8 a[TM], b[TN];
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b[tn] = cell_frag(cur, offb + tn * 2048 + cj[j]);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) a[tm] = cell_frag(cur, offa + tm * 2048 + cj[j]);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  };
-  // branch-free body (a wait whose count depends on a branch becomes vmcnt(0)): NS steps per trip, the steps past nsteps
-  // multiply the zeros of out-of-range loads
-  for (int ks = 0; ks < nsteps; ks += NS) {
-#pragma unroll
-    for (int u = 0; u < NS; ++u) step(bufs[u], bufs[(u + NS - 1) % NS], ks + u + NS - 1);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead pieces (zeros) land before the LDS goes back
-}
-
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-typedef float __attribute__((address_space(3))) * cell_lds_f;
-typedef f32x4v __attribute__((address_space(3))) * cell_lds_f4;
-
-__device__ __forceinline__ unsigned pack_bf2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
-__device__ __forceinline__ void unpack_bf8(const u32x4v v, float (&o)[8]) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    o[2 * k] = __builtin_bit_cast(float, v[k] << 16);
-    o[2 * k + 1] = __builtin_bit_cast(float, v[k] & 0xffff0000u);
-  }
-}
-__device__ __forceinline__ void ld8(const float* p, float (&o)[8]) {
-  const f32x4v a = *(const f32x4v*)p, b = *(const f32x4v*)(p + 4);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) o[k] = a[k], o[4 + k] = b[k];
-}
-__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
-  *(f32x4v*)p = f32x4v{v[0], v[1], v[2], v[3]};
-  *(f32x4v*)(p + 4) = f32x4v{v[4], v[5], v[6], v[7]};
-}
-__device__ __forceinline__ void st8_bf(u16* p, const float (&v)[8]) {
-  *(u32x4v*)p = u32x4v{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-}
 
 // k-step -> (segment, byte offset inside the row)
 struct CellSegs {
@@ -163,7 +67,7 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue = [&](char* stg, int ks) {
+  auto issue = [&](char* stg, int ks, int part) {
     int s = (ks >= end0) + (ks >= end1) + (ks >= end2);  // uniform
     int start = ks >= end0 ? end0 : 0;
     start = ks >= end1 ? end1 : start;
@@ -184,8 +88,8 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
       xa[q] = (rowa0 + (unsigned)(q * 8)) * la + kb;
       xb[q] = (rowb0 + (unsigned)((q >> 1) * H + (q & 1) * 8)) * lb + kb;
     }
-    cell_issue<4>(stg, a, xa, 0u, wave);
-    cell_issue<4>(stg + BM * 128, b, xb, 0u, wave);
+    if (part != 1) cell_issue<4>(stg, a, xa, 0u, wave);
+    if (part != 0) cell_issue<4>(stg + BM * 128, b, xb, 0u, wave);
   };
   cell_mainloop<BM, RB, NS>(acc, nsteps, issue, st0, st1, st2, st3);
   if (dbg & 2) {
@@ -316,7 +220,7 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue = [&](char* stg, int ks) {
+  auto issue = [&](char* stg, int ks, int part) {
     const bool s1 = ks >= sg.n0;
     const unsigned kb = ks < sg.n ? (unsigned)((s1 ? ks - sg.n0 : ks) * (kCellBK * 2)) : kCellOob;
     const __amdgpu_buffer_rsrc_t ra = s1 ? sg.a[1] : sg.a[0], rb = s1 ? sg.b[1] : sg.b[0];
@@ -325,8 +229,8 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
     for (int q = 0; q < NIA; ++q) xa[q] = s1 ? va[1][q] : va[0][q];
 #pragma unroll
     for (int q = 0; q < 2; ++q) xb[q] = s1 ? vb[1][q] : vb[0][q];
-    cell_issue<NIA>(stg, ra, xa, kb, wave);
-    cell_issue<2>(stg + BM * 128, rb, xb, kb, wave);
+    if (part != 1) cell_issue<NIA>(stg, ra, xa, kb, wave);
+    if (part != 0) cell_issue<2>(stg + BM * 128, rb, xb, kb, wave);
   };
   cell_mainloop<BM, BN, NS>(acc, sg.n, issue, st0, st1, st2, st3);
   if (dbg & 2) {

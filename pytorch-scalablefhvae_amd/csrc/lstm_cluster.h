@@ -9,7 +9,9 @@ constexpr int kSyncStatus = 0;    // 0 = ok; bit 0: a bounded spin gave up, bit 
 constexpr int kSyncSticky = 2;    // two words: address of fhvae_lstm_desc.sticky_status (0 = none), written when the block is armed
 constexpr int kSyncXcdCnt = 16;   // 8 arrival counters (one per XCD): ticket & 31 = a workgroup's slot on its XCD, ticket >> 5 = the launch
 constexpr int kSyncFlags = 64;    // + cluster * 32: one word per workgroup of the cluster = the last step it has published
-constexpr int kSyncWordsUsed = kSyncFlags + 64 * 32;
+constexpr int kSyncWordsUsed = 3072;  // the words the operand cast re-arms: the cluster kernels' flags end at kSyncFlags + 64 * 32; the
+                                      // streaming cells (lstm_stream.hip) keep their placement counters behind their flags; the last
+                                      // quarter of the block (from byte 12288) is the phase-clock log of the profiling tools
 // The block is zeroed once per forward (by the operand-cast launch that precedes every bf16 forward); the launches that then
 // share it -- forward chunks, later the backward's, however often it runs -- number themselves: every launch takes 32 tickets
 // of each XCD counter, so launch n holds the tickets [32 n, 32 n + 32) and uses the flag epochs (n * kSeqEpochs, (n + 1) *

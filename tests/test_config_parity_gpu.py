@@ -91,28 +91,32 @@ def test_bench_shape_bf16_lstm_fwd_bwd_vs_torch_lstm(hb, I, Ic):
 
 @pytest.mark.parametrize("B,T,I,Ic", [(256, 6, 80, 32), (256, 5, 80, 0), (384, 4, 0, 64), (1024, 3, 80, 32)])
 def test_big_cells_h512_bf16_vs_torch_lstm_and_generic_cells(hb, monkeypatch, B, T, I, Ic):
-    """The large-tile bf16 step cells (lstm_cell.hip; configs[3] at the bench batch) forced on at a batch the CPU oracle
-    handles: against torch.nn.LSTM with the bf16 tolerances of the tests above, and against the generic step cells on the same
-    inputs (same bf16 operands, f32 accumulation; only the summation order differs): relative Frobenius error < 4e-3."""
+    """The large-tile bf16 cells for H = 512 (configs[3] at the bench batch), forced on at a batch the CPU oracle handles, in both
+    forms -- one launch per wavefront step (lstm_cell.hip, the default) and one persistent launch per direction (lstm_stream.hip,
+    opt-in: FHVAE_STREAM=1) -- against
+    torch.nn.LSTM with the bf16 tolerances of the tests above, and against the generic step cells on the same inputs (same bf16
+    operands, f32 accumulation; only the summation order differs): relative Frobenius error < 4e-3."""
     H, L = 512, 2
     res = {}
-    for big in ("1", "0"):
+    for mode, big, stream in (("stream", "1", "1"), ("cells", "1", "0"), ("generic", "0", "0")):
         monkeypatch.setenv("FHVAE_BIG_CELLS", big)
+        monkeypatch.setenv("FHVAE_STREAM", stream)
         lstm, names, params, (out, hn_cat, xc), (hs_top, hnd, xcd) = _lstm_case(hb, B, T, I, Ic, H, L, "bf16", seed=7 * B + I + Ic)
-        close(hs_top.transpose(0, 1), out, rtol=3e-2, what="hs_top big=" + big)
-        close(hnd, hn_cat, rtol=3e-2, what="hn big=" + big)
+        close(hs_top.transpose(0, 1), out, rtol=3e-2, what="hs_top " + mode)
+        close(hnd, hn_cat, rtol=3e-2, what="hn " + mode)
         got = {"hs_top": hs_top.detach().cpu().double(), "hn": hnd.detach().cpu().double()}
         for p, n in zip(params, names):
-            close(p.grad, getattr(lstm, n).grad, rtol=6e-2, what="d%s big=%s" % (n, big))
+            close(p.grad, getattr(lstm, n).grad, rtol=6e-2, what="d%s %s" % (n, mode))
             got["d" + n] = p.grad.detach().cpu().double()
         if Ic:
-            close(xcd.grad, xc.grad, rtol=6e-2, what="dxc big=" + big)
+            close(xcd.grad, xc.grad, rtol=6e-2, what="dxc " + mode)
             got["dxc"] = xcd.grad.detach().cpu().double()
-        res[big] = got
-    for k in res["1"]:
-        a, b = res["1"][k], res["0"][k]
-        rel = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
-        assert rel < 4e-3, (k, rel)
+        res[mode] = got
+    for mode in ("stream", "cells"):
+        for k in res[mode]:
+            a, b = res[mode][k], res["generic"][k]
+            rel = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+            assert rel < 4e-3, (mode, k, rel)
 
 
 def test_simple_fhvae_z32_vs_oracle(hb):
