@@ -501,7 +501,7 @@ bool stream_eligible(const fhvae_lstm_desc* d) {
   // contraction at a time has the CU's intake) changed neither: a workgroup's contraction is bound by its own bytes in flight
   // (LDS: 64 KB per workgroup at two per CU), not by its neighbour.  The launch-per-step cells stay the default.
   const char* on = getenv("FHVAE_STREAM");
-  if (!on || atoi(on) == 0 || getenv("FHVAE_NO_CLUSTER")) return false;
+  if (!on || atoi(on) == 0) return false;
   if (d->dtype != FHVAE_BF16 || !d->lp) return false;
   if (d->L < 1 || d->L > 2 || d->H % 64 || d->H > 512 || d->H < 64) return false;
   if (d->B % 128 || d->I % 8 || d->Ic % 8 || d->T + 2 >= kSeqEpochs) return false;
