@@ -133,7 +133,8 @@ typedef struct fhvae_lstm_desc {
   float* hs_top_f32; /* (T,B,H) f32 copy of the top layer's h_t (BF16 mode, may be NULL; in F32 mode
                         the top layer is hs + (L-1)*T*B*H and this must be NULL) */
   float* pre;    /* workspace (T,B,4H) f32 (I > 0) or (B,4H) (I == 0): layer-0 input projection (the persistent
-                    schedules only use its first (B,4H): they multiply x_t by W_ih[0] inside the kernel) */
+                    schedules only use its first (B,4H): they multiply x_t by W_ih[0] inside the kernel; the large-tile
+                    bf16 step cells of csrc/lstm_cell.hip multiply the whole layer-0 input themselves and leave it unused) */
   void* lp;      /* BF16 mode: workspace of fhvae_lstm_lp_bytes() bytes; the forward fills it with bf16
                     copies of x, xc, the weights and the transposed weights, the backward reuses it.  It also
                     holds the persistent schedules' sync block (first FHVAE_LSTM_SYNC_BYTES) and their exchange
