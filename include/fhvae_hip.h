@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 4
+#define FHVAE_ABI_VERSION 5
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -145,6 +145,14 @@ typedef struct fhvae_lstm_desc {
 } fhvae_lstm_desc;
 
 int64_t fhvae_lstm_lp_bytes(const fhvae_lstm_desc* d);
+/* Floats the `pre` workspace must hold for this descriptor on the current device (evaluate with `lp` set, as for
+   fhvae_lstm_form): (T,B,4H) for the per-step cells of gemm_core.h with a per-frame input, (B,4H) for the persistent
+   schedules (they multiply x_t inside the kernel), 1 for the large-tile bf16 cells (csrc/lstm_cell.hip: the whole layer-0
+   input projection is theirs; they then REQUIRE 16-byte aligned buffers: the forward returns FHVAE_ERR_ALIGN instead of
+   falling back to a schedule that would need the full buffer).  `pre` must still be non-NULL. */
+int64_t fhvae_lstm_pre_elems(const fhvae_lstm_desc* d);
+/* Floats fhvae_lstm_bwd_desc.ws_below must hold (0: may be NULL). */
+int64_t fhvae_lstm_ws_below_elems(const fhvae_lstm_desc* d);
 /* Which schedule fhvae_lstm_seq_fwd/_bwd take for this descriptor on the current device: 0 = one launch per wavefront
    step; 1 = persistent cluster kernel, waves split the batch rows; 2 = persistent cluster kernel, waves split the
    contraction (small batches).  1 and 2 need the GPU to themselves while they run (256 co-resident workgroups);
@@ -169,9 +177,9 @@ typedef struct fhvae_lstm_bwd_desc {
   int32_t phase;  /* 0: everything; 1: the recurrence (dgates, dgsum, d_xc) only; 2: the weight/bias gradient
                      contractions only (reads what phase 1 left in dgates/dgsum) -- lets the host put phase 2 on a
                      second stream, under the next net's latency-bound recurrence */
-  float* ws_below; /* (T,B,H) f32 workspace, required when fhvae_lstm_form(&f) == 1 and L > 1: the persistent backward runs
-                      layer by layer and hands the from-above gradient dg^{l+1}.W_ih^{l+1} to the lower layer through it
-                      (H = 256: the lower layer's launch computes that term itself and leaves it untouched) */
+  float* ws_below; /* (T,B,H) f32 workspace, required when fhvae_lstm_ws_below_elems(&f) > 0 (persistent backward, layer by
+                      layer, H != 256: the from-above gradient dg^{l+1}.W_ih^{l+1} reaches the lower layer through it;
+                      at H = 256 the lower layer's launch computes that term itself) */
 } fhvae_lstm_bwd_desc;
 
 int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* d, void* stream);

@@ -468,6 +468,13 @@ static bool cell_fwd_plan_ok(const fhvae_lstm_desc* d, const Ops<u16>& op) {
 }
 static bool cell_fwd_plan_ok(const fhvae_lstm_desc*, const Ops<float>&) { return false; }
 
+// the shape part of the large-tile cells' preconditions (what remains is 16-byte alignment of the caller's buffers)
+static bool big_shape_ok(const fhvae_lstm_desc* d) {
+  if (d->dtype != FHVAE_BF16 || d->B % 128 || d->H % 64 || d->I % 8 || d->Ic % 8) return false;
+  if (d->B * 4 * d->H * 4 >= (1LL << 31) || (int64_t)d->L * d->H * d->B * 4 >= (1LL << 31)) return false;
+  return 4 * d->H * (d->I + d->Ic > d->H ? d->I + d->Ic : d->H) * 2 < (1LL << 30);
+}
+
 template <typename T>
 static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t st) {
   const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
@@ -487,6 +494,8 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
   if constexpr (sizeof(T) == 2) {
     stream = !cluster && big_cells(B, H) && stream_eligible(d);  // ... as one persistent launch (lstm_stream.hip)
     cell_big = stream || (!cluster && big_cells(B, H) && cell_fwd_plan_ok(d, op));
+    // fhvae_lstm_pre_elems has promised the caller that `pre` is not needed for this shape
+    if (!cluster && !cell_big && big_cells(B, H) && big_shape_ok(d)) return FHVAE_ERR_ALIGN;
   }
   if (!cell_big && !(fold && Ic == 0) && !xc_in) {
     GemmParams p = {};
@@ -564,6 +573,20 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
 extern "C" int fhvae_lstm_form(const fhvae_lstm_desc* d) {
   if (!d || check_desc(d) != FHVAE_OK || !cluster_eligible(d)) return 0;
   return cluster_form(d);
+}
+
+extern "C" int64_t fhvae_lstm_pre_elems(const fhvae_lstm_desc* d) {
+  if (!d || d->L < 1 || d->L > FHVAE_MAX_LAYERS || d->B <= 0 || d->T <= 0 || d->H <= 0) return 0;
+  const int64_t full = (d->I > 0 ? d->T : 1) * d->B * 4 * d->H;
+  if (d->dtype != FHVAE_BF16) return full;
+  if (cluster_eligible(d)) return (d->I == 0 || cluster_can_fold(d)) ? d->B * 4 * d->H : full;
+  if (big_cells(d->B, d->H) && big_shape_ok(d)) return 1;  // the cells multiply layer 0's input themselves
+  return full;
+}
+
+extern "C" int64_t fhvae_lstm_ws_below_elems(const fhvae_lstm_desc* d) {
+  if (!d || d->dtype != FHVAE_BF16 || d->L < 2) return 0;
+  return cluster_needs_ws_below(d) ? d->T * d->B * d->H : 0;
 }
 
 extern "C" int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream) {

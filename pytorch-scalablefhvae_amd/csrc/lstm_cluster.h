@@ -40,6 +40,8 @@ bool cluster_xc_in_kernel(const fhvae_lstm_desc* d);
 int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st);
 // bd->dgates is (to be) written in the blocked layout [l][t][4H/32][B][32] instead of row-major (L,T,B,4H)
 bool cluster_dg_blocked(const fhvae_lstm_bwd_desc* bd);
+// the backward needs fhvae_lstm_bwd_desc.ws_below
+bool cluster_needs_ws_below(const fhvae_lstm_desc* d);
 // the recurrence of fhvae_lstm_seq_bwd: fills dgates (and dgsum when Ic > 0)
 int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st);
 

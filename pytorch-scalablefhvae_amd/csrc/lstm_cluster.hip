@@ -2128,7 +2128,7 @@ static int launch_bwd_layer_ks(const ClBwd& p, bool blk, hipStream_t st) {
 bool cluster_dg_blocked(const fhvae_lstm_bwd_desc* bd) {
   const fhvae_lstm_desc* d = &bd->f;
   if (!cluster_eligible(d) || cluster_form(d) != 1 || d->H != 256) return false;
-  if (!(d->L == 1 || bd->ws_below) || getenv("FHVAE_NO_LAYERWISE") || getenv("FHVAE_NO_LAYER_KS") || getenv("FHVAE_NO_FUSE_ABOVE")) return false;
+  if (getenv("FHVAE_NO_LAYERWISE") || getenv("FHVAE_NO_LAYER_KS") || getenv("FHVAE_NO_FUSE_ABOVE")) return false;
   // opt-in: measured (c3, B = 2048, interleaved A/B on one device) 930-933 k segments/s with it against 942-945 k without --
   // the 8-byte stores of the blocked copy cost more than the LDS image + whole-line stores of the row-major copy save
   if (getenv("FHVAE_NO_WGRAD") || !getenv("FHVAE_DG_BLOCKED")) return false;
@@ -2203,10 +2203,21 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
   return FHVAE_OK;
 }
 
+// the layer-by-layer backward hands the from-above gradient to the lower layer through bd->ws_below (T,B,H) f32 -- unless the
+// lower layer's launch computes that term itself (H = 256, contraction-split kernels)
+bool cluster_needs_ws_below(const fhvae_lstm_desc* d) {
+  if (!cluster_eligible(d) || cluster_form(d) != 1 || d->L < 2 || getenv("FHVAE_NO_LAYERWISE")) return false;
+  const bool ks = d->H == 256 && !getenv("FHVAE_NO_LAYER_KS");
+  return !(ks && !getenv("FHVAE_NO_FUSE_ABOVE"));
+}
+
 int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;
   const int H = (int)d->H, L = d->L;
-  if (cluster_form(d) == 1 && (L == 1 || bd->ws_below) && !getenv("FHVAE_NO_LAYERWISE")) return cluster_bwd_layers(bd, w, st);
+  if (cluster_form(d) == 1 && !getenv("FHVAE_NO_LAYERWISE")) {
+    if (cluster_needs_ws_below(d) && !bd->ws_below) return FHVAE_ERR_NULL;  // (fhvae_lstm_ws_below_elems says when)
+    return cluster_bwd_layers(bd, w, st);
+  }
   const int NU = H / 16, NC = kGrid / NU;
   const int64_t chunk = (int64_t)NC * 128;
   for (int64_t row0 = 0; row0 < d->B; row0 += chunk) {

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
 
 F32, BF16 = 0, 1
 MAX_LAYERS = 4
-ABI_VERSION = 4  # FHVAE_ABI_VERSION of include/fhvae_hip.h
+ABI_VERSION = 5  # FHVAE_ABI_VERSION of include/fhvae_hip.h
 #: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
 INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
@@ -87,6 +87,8 @@ SIGNATURES = {
     "fhvae_loss_bwd": (C.c_int, [_vp, _f32, _vp, _vp, _i64, _vp]),
     "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_form": (C.c_int, [C.POINTER(LstmDesc)]),
+    "fhvae_lstm_pre_elems": (_i64, [C.POINTER(LstmDesc)]),
+    "fhvae_lstm_ws_below_elems": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
     "fhvae_lstm_seq_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), _vp]),
     "fhvae_lstm_param_grads_multi": (C.c_int, [C.POINTER(C.POINTER(LstmBwdDesc)), C.c_int, _vp]),
@@ -611,7 +613,6 @@ class _LstmSeq(torch.autograd.Function):
         cs = torch.empty(L, T, B, H, **f32)
         gates = torch.empty(L, T, B, 4 * H, device=dev, dtype=hs.dtype)
         hn = torch.empty(B, L * H, **f32)
-        pre = torch.empty((T if I > 0 else 1), B, 4 * H, **f32)
         if not bf:
             top = 2
         hs_top = torch.empty(T, B, H, **f32) if (bf and top != 0) else None
@@ -624,7 +625,10 @@ class _LstmSeq(torch.autograd.Function):
             LSTM_WORKSPACES.append(lp)
             del LSTM_WORKSPACES[:-16]
             d.lp = _p(lp)
-        d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.pre, d.lp = _p(hs), _p(cs), _p(gates), _p(hn), _p(hs_top if top == 2 else None), _p(pre), _p(lp)
+        d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.lp = _p(hs), _p(cs), _p(gates), _p(hn), _p(hs_top if top == 2 else None), _p(lp)
+        # layer-0 input projection workspace: (T,B,4H) only for the schedules that read it (168 MB per net at B = 2048, H = 256)
+        pre = torch.empty(max(1, int(lib.fhvae_lstm_pre_elems(C.byref(d)))), **f32)
+        d.pre = _p(pre)
         LAST_LSTM_FORM["form"] = int(lib.fhvae_lstm_form(C.byref(d)))
         with _Timed("fhvae_lstm_seq_fwd"):
             _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")
@@ -667,7 +671,8 @@ class _LstmSeq(torch.autograd.Function):
         for l in range(L):
             bd.dw_ih[l], bd.dw_hh[l], bd.db_ih[l], bd.db_hh[l] = (_p(grads[4 * l + k]) for k in range(4))
         bd.d_xc = _p(d_xc)
-        ws_below = torch.empty(T, B, H, **f32) if (ctx.dtype == BF16 and L > 1) else None
+        n_below = int(lib.fhvae_lstm_ws_below_elems(C.byref(d)))
+        ws_below = torch.empty(n_below, **f32) if n_below > 0 else None
         bd.ws_below = _p(ws_below)
         if (_DEFER["enabled"] and not _SIDE["enabled"] and all(sk is not None for sk in ctx.sinks)):
             # recurrence now; the parameter gradients with those of the other nets at the optimizer (flush_param_grads)
