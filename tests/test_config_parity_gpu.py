@@ -206,12 +206,16 @@ def test_fhvae_h256_f32_outputs_elementwise(hb):
         close_elementwise(got[k], want[k], what=n)
 
 
-def test_fhvae_h512_bf16_tracks_f32_oracle(hb):
-    """configs[3]'s model (2x512, z = 32) in bf16 against the f32 oracle: "matched ELBO" tolerance 1e-2 on the outputs."""
+@pytest.mark.parametrize("B,big", [(64, None), (128, "1")])
+def test_fhvae_h512_bf16_tracks_f32_oracle(hb, monkeypatch, B, big):
+    """configs[3]'s model (2x512, z = 32) in bf16 against the f32 oracle: "matched ELBO" tolerance 1e-2 on the outputs.  B = 64:
+    the generic step cells; B = 128 with the large-tile cells forced on (lstm_cell.hip: what configs[3] runs at its batch)."""
     from fhvae import FHVAE
     from train_model import loss_function
 
-    T, F, H, D, B, S = 20, 80, 512, 32, 64, 500
+    if big:
+        monkeypatch.setenv("FHVAE_BIG_CELLS", big)
+    T, F, H, D, S = 20, 80, 512, 32, 500
     torch.manual_seed(512)
     ref = R.FHVAERef(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T)
     m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T, reference_compat=False, compute_dtype="bf16")
