@@ -128,7 +128,9 @@ typedef struct fhvae_lstm_desc {
   /* forward outputs, saved for backward */
   void* hs;      /* (L,T,B,H) in the operand dtype (f32 or bf16): h^l_t */
   float* cs;     /* (L,T,B,H) f32: c^l_t */
-  void* gates;   /* (L,T,B,4H) in the operand dtype: activated i,f,g,o (column blocks of H) */
+  void* gates;   /* (L,T,B,4H) in the operand dtype: activated i,f,g,o.  A workspace between a forward and ITS backward: the
+                    per-step cells keep column blocks of H per gate, the persistent schedules keep the four gates of a unit
+                    quad together (csrc/lstm_cluster.hip, cl_goff); do not read it from outside */
   float* hn;     /* (B, L*H) f32: final hidden state of every layer, concatenated (may be NULL) */
   float* hs_top_f32; /* (T,B,H) f32 copy of the top layer's h_t (BF16 mode, may be NULL; in F32 mode
                         the top layer is hs + (L-1)*T*B*H and this must be NULL) */

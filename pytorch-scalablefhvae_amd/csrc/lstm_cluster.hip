@@ -163,6 +163,22 @@ __device__ __forceinline__ int64_t xch_off(int par, int l, int L, int KS, int ks
   return ((((int64_t)par * L + l) * KS + ks) * B + row) * 32;
 }
 
+// Layout of the saved activated gates in the persistent schedules (fhvae_lstm_desc.gates is a workspace: forward and backward of
+// a net always take the same schedule; the per-step cells keep [row][gate][H]).  Within a row, the 16 units of block u >> 4
+// occupy 64 elements: [gates 0,1 | gates 2,3][unit quad][gate of the pair][4 units].  A lane's 4 units x 4 gates are then two
+// 16-byte pieces (they were four 8-byte pieces at the stride H), and the 16 units x 4 gates of a forward member are ONE 128-byte
+// line per row: the forward's saved-for-backward stores (20 partial-line instructions per wave and step, ~130 ns each: the
+// 2.6-us tail of every step) become 12 that fill whole lines.
+__device__ __forceinline__ int cl_goff(int uq) { return (uq >> 4) * 64 + ((uq >> 2) & 3) * 8; }
+__device__ __forceinline__ void cl_load_gates(const u16* row_base, int uq, uint2 (&g)[4]) {
+  const uint4 a = *(const uint4*)(row_base + cl_goff(uq)), b = *(const uint4*)(row_base + cl_goff(uq) + 32);
+  g[0] = uint2{a.x, a.y}, g[1] = uint2{a.z, a.w}, g[2] = uint2{b.x, b.y}, g[3] = uint2{b.z, b.w};
+}
+__device__ __forceinline__ void cl_store_gates(u16* row_base, int uq, const uint2 (&g)[4]) {
+  *(uint4*)(row_base + cl_goff(uq)) = uint4{g[0].x, g[0].y, g[1].x, g[1].y};
+  *(uint4*)(row_base + cl_goff(uq) + 32) = uint4{g[2].x, g[2].y, g[3].x, g[3].y};
+}
+
 // wait until at most `younger` panels (4 DMA instructions each) issued after the needed one are still in flight
 __device__ __forceinline__ void wait_panels(int younger) {
   if (younger >= 2)
@@ -314,9 +330,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
         const int row = r0 + wrow0 + tm * 16 + r;
         if (row >= rend) continue;
         *(f32x4*)(p.cs + (lt * B + row) * H + uq) = creg[ll][tm];
-        u16* go = p.gates + (lt * B + row) * (4 * H) + uq;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = gpk[ll][tm][g];
+        cl_store_gates(p.gates + (lt * B + row) * (4 * H), uq, gpk[ll][tm]);
         if (ll == L - 1 && p.hs_top_f32) *(f32x4*)(p.hs_top_f32 + ((int64_t)t * B + row) * H + uq) = hreg[ll][tm];
         if (p.hn && t == T - 1) *(f32x4*)(p.hn + (int64_t)row * (L * H) + ll * H + uq) = hreg[ll][tm];
       }
@@ -618,7 +632,11 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     // (5) publish step s (also the barrier that frees the staging buffers for the next step)
     if (s + 1 < nsteps) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));
     CL_TLOG(s * 8 + 4);
-    tail_stores(s);  // (6) off the critical path, under the next step's wait
+    // (6) what only the backward reads.  Not free: 20 partial-line store instructions per wave and step cost the wave ~130 ns
+    // each wherever they are issued -- as this burst (2.6 us before the next flag poll), all behind the next step's first
+    // panel issues (228 us per launch against 204), or two or three behind every panel issue of the next step (226): the
+    // panels queue behind them.  Fewer, fuller stores are what helps (the gate layout, cl_goff).
+    tail_stores(s);
   }
 }
 
@@ -754,9 +772,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
       for (int tm = 0; tm < TM; ++tm) {
         const int row0_ = r0 + wrow0 + tm * 16 + r;
         const int64_t row = row0_ < rend ? row0_ : rend - 1;
-        const u16* gp = p.gates + (lt * B + row) * G + uq;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gk[l][tm][g] = *(const uint2*)(gp + g * H);
+        cl_load_gates(p.gates + (lt * B + row) * G, uq, gk[l][tm]);
         if (t == T - 1) ccur[l][tm] = *(const f32x4*)(p.cs + (lt * B + row) * H + uq);
         cprev[l][tm] = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + row) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -969,9 +985,12 @@ __global__ __launch_bounds__(HW ? kThreads + 64 : kThreads) void lstm_bwd_layer_
         const int rl = lane >> 2, piece = lane & 3;
         const int row0_ = r0 + w * 16 + rl;
         const int64_t row = row0_ < rend ? row0_ : rend - 1;
+        // the member's 32 units = two 128-byte blocks of the row (cl_goff): image [16 rows][256 B], four rows per instruction
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const u16* src = p.gates + ((int64_t)t * B + row) * G + g * H + u0 + piece * 8;
+          const int row4_ = r0 + w * 16 + g * 4 + (lane >> 4);
+          const int64_t row4 = row4_ < rend ? row4_ : rend - 1;
+          const u16* src = p.gates + ((int64_t)t * B + row4) * G + (u0 >> 4) * 64 + (lane & 15) * 8;
           __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                            (void __attribute__((address_space(3)))*)(op + g * 1024), 16, 0, 0);
         }
@@ -1027,8 +1046,10 @@ __global__ __launch_bounds__(HW ? kThreads + 64 : kThreads) void lstm_bwd_layer_
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
           const int ul = ut * 16 + q * 4, uq = u0 + ul;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) gk[0][ut][g] = *(const uint2*)(op + g * 1024 + r * 64 + ul * 2);
+          {
+            const uint4 ga = *(const uint4*)(op + r * 256 + ut * 128 + q * 16), gb = *(const uint4*)(op + r * 256 + ut * 128 + 64 + q * 16);
+            gk[0][ut][0] = uint2{ga.x, ga.y}, gk[0][ut][1] = uint2{ga.z, ga.w}, gk[0][ut][2] = uint2{gb.x, gb.y}, gk[0][ut][3] = uint2{gb.z, gb.w};
+          }
           cprev[0][ut] = t > 0 ? *(const f32x4*)(op + 4096 + r * 128 + ul * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
           f32x4 e = p.d_hs_top ? *(const f32x4*)(op + 6144 + r * 128 + ul * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
           if (s == 0) {
@@ -1049,9 +1070,7 @@ __global__ __launch_bounds__(HW ? kThreads + 64 : kThreads) void lstm_bwd_layer_
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
           const int uq = u0 + ut * 16 + q * 4;
-          const u16* gp = p.gates + ((int64_t)t * B + row) * G + uq;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) gk[tm][ut][g] = *(const uint2*)(gp + g * H);
+          cl_load_gates(p.gates + ((int64_t)t * B + row) * G, uq, gk[tm][ut]);
           if (s == 0) ccur[tm][ut] = *(const f32x4*)(p.cs + ((int64_t)t * B + row) * H + uq);
           cprev[tm][ut] = t > 0 ? *(const f32x4*)(p.cs + ((int64_t)(t - 1) * B + row) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
           f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1406,9 +1425,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
     if (act && row < rend) {
       const int64_t lt = (int64_t)kp * T + t;
       *(f32x4*)(p.cs + (lt * B + row) * H + uq) = creg;
-      u16* go = p.gates + (lt * B + row) * (4 * H) + uq;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = gpk[g];
+      cl_store_gates(p.gates + (lt * B + row) * (4 * H), uq, gpk);
       if (kp == L - 1 && p.hs_top_f32) *(f32x4*)(p.hs_top_f32 + ((int64_t)t * B + row) * H + uq) = hreg;
       if (p.hn && t == T - 1) *(f32x4*)(p.hn + (int64_t)row * (L * H) + kp * H + uq) = hreg;
     }
@@ -1472,9 +1489,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
     const int t = T - 1 - (sn - (L - 1 - kp));
     if (!(epi && t >= 0 && t < T)) return;
     const int64_t lt = (int64_t)kp * T + t;
-    const u16* gp = p.gates + (lt * B + rowc) * G + uq;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) gkn[g] = *(const uint2*)(gp + g * H);
+    cl_load_gates(p.gates + (lt * B + rowc) * G, uq, gkn);
     if (t == T - 1) ccurn = *(const f32x4*)(p.cs + (lt * B + rowc) * H + uq);
     cprevn = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + rowc) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
     extn = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1688,9 +1703,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
     const int t = T - 1 - sn;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const u16* gp = p.gates + ((int64_t)t * B + rowc[rt]) * G + uq;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gkn[rt][g] = *(const uint2*)(gp + g * H);
+      cl_load_gates(p.gates + ((int64_t)t * B + rowc[rt]) * G, uq, gkn[rt]);
       if (sn == 0) ccurn[rt] = *(const f32x4*)(p.cs + ((int64_t)t * B + rowc[rt]) * H + uq);
       cprevn[rt] = t > 0 ? *(const f32x4*)(p.cs + ((int64_t)(t - 1) * B + rowc[rt]) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
