@@ -635,7 +635,9 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     // (6) what only the backward reads.  Not free: 20 partial-line store instructions per wave and step cost the wave ~130 ns
     // each wherever they are issued -- as this burst (2.6 us before the next flag poll), all behind the next step's first
     // panel issues (228 us per launch against 204), or two or three behind every panel issue of the next step (226): the
-    // panels queue behind them.  Fewer, fuller stores are what helps (the gate layout, cl_goff).
+    // panels queue behind them; or four behind each of the next step's last three panel waits, i.e. behind its last panel
+    // issue and ~1.5 us ahead of the h stores (201 against 190, with the cl_goff layout): a wave whose store queue is full
+    // stalls its MFMAs too.  Fewer, fuller stores are what helps (the gate layout, cl_goff).
     tail_stores(s);
   }
 }
