@@ -137,7 +137,10 @@ typedef struct fhvae_lstm_desc {
   float* pre;    /* workspace (T,B,4H) f32 (I > 0) or (B,4H) (I == 0): layer-0 input projection (the persistent
                     schedules only use its first (B,4H): they multiply x_t by W_ih[0] inside the kernel; the large-tile
                     bf16 step cells of csrc/lstm_cell.hip multiply the whole layer-0 input themselves and leave it unused) */
-  void* lp;      /* BF16 mode: workspace of fhvae_lstm_lp_bytes() bytes; the forward fills it with bf16
+  void* lp;      /* F32 mode: optional workspace of fhvae_lstm_lp_bytes() bytes (may be NULL): the forward leaves the
+                    transposed f32 weights in it and the backward cells then stage both operands by LDS-DMA (64 -> 40 us per
+                    launch at B = 2048, H = 256); without it they read the master weights as K-major operands.
+                    BF16 mode: workspace of fhvae_lstm_lp_bytes() bytes; the forward fills it with bf16
                     copies of x, xc, the weights and the transposed weights, the backward reuses it.  It also
                     holds the persistent schedules' sync block (first FHVAE_LSTM_SYNC_BYTES) and their exchange
                     buffer (2*L*B*4H bf16): keep it alive and untouched between the forward and its backward */

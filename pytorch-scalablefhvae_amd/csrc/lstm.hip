@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
   constexpr int TM = TL::TM, TN = TL::TN;
   constexpr int NBUF = CH >= 32 ? 2 : 1;
   using GT = GldsTile<T, BM, BN, WM, WN, CH, NBUF>;
-  __shared__ __attribute__((aligned(16))) char smem[(sizeof(T) == 2 && GT::SMEM > TL::SMEM) ? GT::SMEM : TL::SMEM];
+  __shared__ __attribute__((aligned(16))) char smem[GT::SMEM > TL::SMEM ? GT::SMEM : TL::SMEM];
   const BwdJob<T>& J = jobs.job[blockIdx.z];
   const int B = jobs.B, H = jobs.H;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // row tiles on x: XCD-local activations (see the forward cell)
@@ -164,14 +164,16 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int nkb = num_kblocks<T, CH>(J.seg);
-  // f32: W is the untransposed master weight (KM operand); bf16: the transposed bf16 copy (KC operand) -> LDS-DMA path
-  bool dma = false;
-  if constexpr (sizeof(T) == 2)
-    dma = jobs.glds && m0 + BM <= B && n0 + BN <= H && seg_glds_ok<T>(J.seg[0], TL::BK) && seg_glds_ok<T>(J.seg[1], TL::BK);
+  // W: the transposed copy [H,4H] (KC operand: bf16 always, f32 when the caller gave the forward a workspace) -> LDS-DMA path;
+  // else (f32) the untransposed master weight as a KM operand
+  const bool wkc = (J.seg[0].K == 0 || J.seg[0].b_kc) && (J.seg[1].K == 0 || J.seg[1].b_kc);
+  const bool dma = wkc && jobs.glds && m0 + BM <= B && n0 + BN <= H && seg_glds_ok<T>(J.seg[0], TL::BK) && seg_glds_ok<T>(J.seg[1], TL::BK);
   if (dma) {
-    if constexpr (sizeof(T) == 2) mainloop_glds<T, BM, BN, WM, WN, CH, NBUF, false>(acc, J.seg, m0, n0, arm, brm, smem);
+    mainloop_glds<T, BM, BN, WM, WN, CH, NBUF, false>(acc, J.seg, m0, n0, arm, brm, smem);
+  } else if (wkc) {
+    mainloop<T, BM, BN, WM, WN, CH, true, true, false>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
   } else {
-    mainloop<T, BM, BN, WM, WN, CH, true, sizeof(T) == 2, false>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
+    if constexpr (sizeof(T) == 4) mainloop<T, BM, BN, WM, WN, CH, true, false, false>(acc, J.seg, m0, B, n0, H, arm, brm, 0, nkb, smem);
   }
 
 #pragma unroll
@@ -264,6 +266,38 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(CastBatch cb) {
   }
 }
 
+// f32 [R,C] -> f32 [C,R] through a 32x32 LDS tile (the transposed weights of the f32 backward cells), one item per blockIdx.y
+struct TransItem {
+  const float* src;
+  float* dst_t;
+  int64_t R, C;
+};
+struct TransBatch {
+  int n;
+  TransItem it[2 * FHVAE_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void transpose_f32_kernel(TransBatch tb) {
+  __shared__ float tile[32][33];
+  const TransItem& c = tb.it[blockIdx.y];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t tr = (c.R + 31) / 32, tc = (c.C + 31) / 32;
+  for (int64_t t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int64_t r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t r = r0 + ty + 8 * k, cc = c0 + tx;
+      tile[ty + 8 * k][tx] = (r < c.R && cc < c.C) ? c.src[r * c.C + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t cc = c0 + ty + 8 * k, r = r0 + tx;
+      if (cc < c.C && r < c.R) c.dst_t[cc * c.R + r] = tile[tx][ty + 8 * k];
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void zero_f32_kernel(float* p, int64_t n) {
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4)
     for (int k = 0; k < 4 && i + k < n; ++k) p[i + k] = 0.f;
@@ -336,8 +370,31 @@ static LpLayout lp_layout(const fhvae_lstm_desc* d) {
   return o;
 }
 
+// f32 mode: the optional workspace holds the TRANSPOSED f32 weights [H,4H] the backward cells multiply by (float offsets; the
+// sync block's bytes are skipped so that both modes keep the same head)
+struct Lp32Layout {
+  int64_t w_ih_t[FHVAE_MAX_LAYERS], w_hh_t[FHVAE_MAX_LAYERS], total;
+};
+static Lp32Layout lp32_layout(const fhvae_lstm_desc* d) {
+  Lp32Layout o;
+  int64_t n = FHVAE_LSTM_SYNC_BYTES / 4;
+  auto take = [&](int64_t cnt) {
+    int64_t at = n;
+    n += (cnt + 3) / 4 * 4;
+    return at;
+  };
+  for (int l = 0; l < d->L; ++l) {
+    o.w_ih_t[l] = take(l == 0 ? 0 : 4 * d->H * d->H);
+    o.w_hh_t[l] = take(4 * d->H * d->H);
+  }
+  o.total = n;
+  return o;
+}
+
 extern "C" int64_t fhvae_lstm_lp_bytes(const fhvae_lstm_desc* d) {
-  if (!d || d->dtype != FHVAE_BF16 || d->L < 1 || d->L > FHVAE_MAX_LAYERS) return 0;
+  if (!d || d->L < 1 || d->L > FHVAE_MAX_LAYERS) return 0;
+  if (d->dtype == FHVAE_F32) return lp32_layout(d).total * 4;
+  if (d->dtype != FHVAE_BF16) return 0;
   return lp_layout(d).total * 2;
 }
 
@@ -358,6 +415,14 @@ static Ops<float> ops_f32(const fhvae_lstm_desc* d) {
   for (int l = 0; l < d->L; ++l) {
     o.w_ih[l] = d->w_ih[l];
     o.w_hh[l] = d->w_hh[l];
+  }
+  if (d->lp) {  // transposed copies (filled by the forward): the backward cells then take the LDS-DMA KC/KC path
+    const Lp32Layout Y = lp32_layout(d);
+    const float* base = (const float*)d->lp;
+    for (int l = 0; l < d->L; ++l) {
+      o.w_ih_t[l] = l > 0 ? base + Y.w_ih_t[l] : nullptr;
+      o.w_hh_t[l] = base + Y.w_hh_t[l];
+    }
   }
   return o;
 }
@@ -593,7 +658,21 @@ extern "C" int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream) {
   int e = check_desc(d);
   if (e) return e;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == FHVAE_F32) return lstm_fwd_impl<float>(d, ops_f32(d), st);
+  if (d->dtype == FHVAE_F32) {
+    if (d->lp) {
+      const Lp32Layout Y = lp32_layout(d);
+      float* base = (float*)d->lp;
+      TransBatch tb = {};
+      for (int l = 0; l < d->L; ++l) {
+        if (l > 0) tb.it[tb.n++] = TransItem{d->w_ih[l], base + Y.w_ih_t[l], 4 * d->H, d->H};
+        tb.it[tb.n++] = TransItem{d->w_hh[l], base + Y.w_hh_t[l], 4 * d->H, d->H};
+      }
+      hipLaunchKernelGGL(transpose_f32_kernel, dim3(256, (unsigned)tb.n), dim3(256), 0, (hipStream_t)stream, tb);
+      e = fh_launch_status();
+      if (e) return e;
+    }
+    return lstm_fwd_impl<float>(d, ops_f32(d), st);
+  }
   e = cast_operands(d, st);
   if (e) return e;
   return lstm_fwd_impl<u16>(d, ops_bf16(d), st);
@@ -621,13 +700,13 @@ static BwdJobs<T> bwd_jobs(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, int6
     const int64_t lt = (int64_t)l * T_ + t;
     if (t < T_ - 1) {
       const T* a = dg + (lt + 1) * B * 4 * H;
-      J.seg[0] = kF32 ? Seg{a, 4 * H, 1, op.w_hh[l], H, 0, (int)(4 * H), 0}
-                      : Seg{a, 4 * H, 1, op.w_hh_t[l], 4 * H, 1, (int)(4 * H), 0};
+      J.seg[0] = (kF32 && !op.w_hh_t[l]) ? Seg{a, 4 * H, 1, op.w_hh[l], H, 0, (int)(4 * H), 0}
+                                         : Seg{a, 4 * H, 1, op.w_hh_t[l], 4 * H, 1, (int)(4 * H), 0};
     }
     if (l < L - 1) {
       const T* a = dg + ((int64_t)(l + 1) * T_ + t) * B * 4 * H;
-      J.seg[1] = kF32 ? Seg{a, 4 * H, 1, op.w_ih[l + 1], H, 0, (int)(4 * H), 0}
-                      : Seg{a, 4 * H, 1, op.w_ih_t[l + 1], 4 * H, 1, (int)(4 * H), 0};
+      J.seg[1] = (kF32 && !op.w_ih_t[l + 1]) ? Seg{a, 4 * H, 1, op.w_ih[l + 1], H, 0, (int)(4 * H), 0}
+                                             : Seg{a, 4 * H, 1, op.w_ih_t[l + 1], 4 * H, 1, (int)(4 * H), 0};
     }
     if (l == L - 1 && bd->d_hs_top) {
       J.ext = bd->d_hs_top + t * B * H;

@@ -619,12 +619,12 @@ class _LstmSeq(torch.autograd.Function):
         d = LstmDesc()
         dims = (L, B, T, I, Ic, H)
         _fill_lstm_desc(d, dtype, dims, x_tm, xc, params, x_lp)
-        lp = None
+        # workspace: bf16 operand copies + sync block (bf16 mode) / transposed f32 weights for the backward cells (f32 mode)
+        lp = torch.empty(int(lib.fhvae_lstm_lp_bytes(C.byref(d))), device=dev, dtype=torch.uint8)
         if bf:
-            lp = torch.empty(int(lib.fhvae_lstm_lp_bytes(C.byref(d))), device=dev, dtype=torch.uint8)
             LSTM_WORKSPACES.append(lp)
             del LSTM_WORKSPACES[:-16]
-            d.lp = _p(lp)
+        d.lp = _p(lp)
         d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.lp = _p(hs), _p(cs), _p(gates), _p(hn), _p(hs_top if top == 2 else None), _p(lp)
         # layer-0 input projection workspace: (T,B,4H) only for the schedules that read it (168 MB per net at B = 2048, H = 256)
         pre = torch.empty(max(1, int(lib.fhvae_lstm_pre_elems(C.byref(d)))), **f32)
