@@ -461,13 +461,13 @@ static int cast_operands(const fhvae_lstm_desc* d, hipStream_t st) {
   return fh_launch_status();
 }
 
-// the large-tile bf16 cells (lstm_cell.hip) take a wavefront step once it offers them about a workgroup per CU
-// (FHVAE_BIG_CELLS=0/1 overrides)
-static bool big_cells(int64_t B, int64_t H) {
+// the large-tile cells (lstm_cell.hip) take a wavefront step once it offers them about a workgroup per CU (f32, whose
+// generic cells are further from their roofline: from 256 tiles per launch); FHVAE_BIG_CELLS=0/1 overrides
+static bool big_cells(int64_t B, int64_t H, int dtype = FHVAE_BF16) {
   const char* ev = getenv("FHVAE_BIG_CELLS");  // read per call: the tests flip it
   const int env = ev ? atoi(ev) : -1;
   if (env >= 0) return env != 0;
-  return (B / 128) * (H / 64) >= 96;
+  return (B / 128) * (H / 64) >= (dtype == FHVAE_F32 ? 64 : 96);
 }
 
 static StreamWeights stream_weights(const Ops<u16>& op) {
@@ -523,21 +523,22 @@ static FwdJobs<T> fwd_jobs(const fhvae_lstm_desc* d, const Ops<T>& op, int64_t w
 }
 
 // every wavefront step of the sequence meets the large-tile cells' preconditions
-static bool cell_fwd_plan_ok(const fhvae_lstm_desc* d, const Ops<u16>& op) {
+template <typename T>
+static bool cell_fwd_plan_ok(const fhvae_lstm_desc* d, const Ops<T>& op) {
   for (int64_t w = 0; w < d->T + d->L - 1; ++w) {
     int nj = 0;
-    const FwdJobs<u16> jobs = fwd_jobs<u16>(d, op, w, true, nj);
+    const FwdJobs<T> jobs = fwd_jobs<T>(d, op, w, true, nj);
     if (!cell_fwd_big_ok(jobs, nj)) return false;
   }
   return true;
 }
-static bool cell_fwd_plan_ok(const fhvae_lstm_desc*, const Ops<float>&) { return false; }
 
 // the shape part of the large-tile cells' preconditions (what remains is 16-byte alignment of the caller's buffers)
 static bool big_shape_ok(const fhvae_lstm_desc* d) {
-  if (d->dtype != FHVAE_BF16 || d->B % 128 || d->H % 64 || d->I % 8 || d->Ic % 8) return false;
+  const int es = d->dtype == FHVAE_BF16 ? 2 : 4, epc = 16 / es;
+  if (d->B % 128 || d->H % 64 || d->I % epc || d->Ic % epc) return false;
   if (d->B * 4 * d->H * 4 >= (1LL << 31) || (int64_t)d->L * d->H * d->B * 4 >= (1LL << 31)) return false;
-  return 4 * d->H * (d->I + d->Ic > d->H ? d->I + d->Ic : d->H) * 2 < (1LL << 30);
+  return 4 * d->H * (d->I + d->Ic > d->H ? d->I + d->Ic : d->H) * es < (1LL << 30);
 }
 
 template <typename T>
@@ -556,12 +557,10 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
   }
   // large-tile step cells (lstm_cell.hip; all steps of the sequence or none): they multiply layer 0's input themselves
   bool cell_big = false, stream = false;
-  if constexpr (sizeof(T) == 2) {
-    stream = !cluster && big_cells(B, H) && stream_eligible(d);  // ... as one persistent launch (lstm_stream.hip)
-    cell_big = stream || (!cluster && big_cells(B, H) && cell_fwd_plan_ok(d, op));
-    // fhvae_lstm_pre_elems has promised the caller that `pre` is not needed for this shape
-    if (!cluster && !cell_big && big_cells(B, H) && big_shape_ok(d)) return FHVAE_ERR_ALIGN;
-  }
+  if constexpr (sizeof(T) == 2) stream = !cluster && big_cells(B, H) && stream_eligible(d);  // ... as one persistent launch (lstm_stream.hip)
+  cell_big = stream || (!cluster && big_cells(B, H, d->dtype) && cell_fwd_plan_ok(d, op));
+  // fhvae_lstm_pre_elems has promised the caller that `pre` is not needed for this shape
+  if (!cluster && !cell_big && big_cells(B, H, d->dtype) && big_shape_ok(d)) return FHVAE_ERR_ALIGN;
   if (!cell_big && !(fold && Ic == 0) && !xc_in) {
     GemmParams p = {};
     int s = 0;
@@ -589,10 +588,12 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
   }
   if constexpr (sizeof(T) == 2) {
     if (stream) return stream_fwd(d, stream_weights(op), st);
+  }
+  {
     if (cell_big) {  // large-tile cells (lstm_cell.hip)
       for (int64_t w = 0; w < T_ + L - 1; ++w) {
         int nj = 0;
-        const FwdJobs<u16> jobs = fwd_jobs(d, op, w, true, nj);
+        const FwdJobs<T> jobs = fwd_jobs(d, op, w, true, nj);
         double fl = 0;
         for (int j = 0; j < nj; ++j)
           fl += 2.0 * B * 4 * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K + jobs.job[j].xseg[0].K + jobs.job[j].xseg[1].K);
@@ -643,9 +644,8 @@ extern "C" int fhvae_lstm_form(const fhvae_lstm_desc* d) {
 extern "C" int64_t fhvae_lstm_pre_elems(const fhvae_lstm_desc* d) {
   if (!d || d->L < 1 || d->L > FHVAE_MAX_LAYERS || d->B <= 0 || d->T <= 0 || d->H <= 0) return 0;
   const int64_t full = (d->I > 0 ? d->T : 1) * d->B * 4 * d->H;
-  if (d->dtype != FHVAE_BF16) return full;
-  if (cluster_eligible(d)) return (d->I == 0 || cluster_can_fold(d)) ? d->B * 4 * d->H : full;
-  if (big_cells(d->B, d->H) && big_shape_ok(d)) return 1;  // the cells multiply layer 0's input themselves
+  if (d->dtype == FHVAE_BF16 && cluster_eligible(d)) return (d->I == 0 || cluster_can_fold(d)) ? d->B * 4 * d->H : full;
+  if (big_cells(d->B, d->H, d->dtype) && big_shape_ok(d)) return 1;  // the cells multiply layer 0's input themselves
   return full;
 }
 
@@ -727,10 +727,13 @@ static BwdJobs<T> bwd_jobs(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, int6
   return jobs;
 }
 
-static bool cell_bwd_plan_ok(const fhvae_lstm_bwd_desc* bd, const Ops<u16>& op) {
+template <typename T>
+static bool cell_bwd_plan_ok(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op) {
+  for (int l = 0; l < bd->f.L; ++l)
+    if (!op.w_hh_t[l] || (l > 0 && !op.w_ih_t[l])) return false;  // (f32 without the workspace: no transposed weights)
   for (int64_t w = 0; w < bd->f.T + bd->f.L - 1; ++w) {
     int nj = 0;
-    const BwdJobs<u16> jobs = bwd_jobs<u16>(bd, op, w, nj);
+    const BwdJobs<T> jobs = bwd_jobs<T>(bd, op, w, nj);
     if (!cell_bwd_big_ok(jobs, nj)) return false;
   }
   return true;
@@ -755,23 +758,23 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
       if (Ic > 0) return launch_cell_dgsum((const u16*)bd->dgates, bd->dgsum, (int)T_, B * 4 * H, st);
       return FHVAE_OK;
     }
-    if (big_cells(B, H) && cell_bwd_plan_ok(bd, op)) {
-      // large-tile cells (lstm_cell.hip); they leave the time sum of layer 0's gate gradients to one pass over the saved
-      // bf16 dgates.  (Tried: the batch rows as 2 / 4 independent launch chains on side streams, so that one chain's
-      // HBM-bound epilogue would run beside the other's contraction: 348 k / 312 k segments/s against 361 k for one chain.)
-      for (int64_t w = 0; w < T_ + L - 1; ++w) {
-        int nj = 0;
-        const BwdJobs<u16> jobs = bwd_jobs<u16>(bd, op, w, nj);
-        double fl = 0;
-        for (int j = 0; j < nj; ++j) fl += 2.0 * B * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
-        const int ts = trace_begin(st, kTraceBwdCell, fl);
-        const int e = launch_cell_bwd_big(jobs, nj, st);
-        trace_end(st, ts);
-        if (e) return e;
-      }
-      if (Ic > 0) return launch_cell_dgsum((const u16*)bd->dgates, bd->dgsum, (int)T_, B * 4 * H, st);
-      return FHVAE_OK;
+  }
+  if (big_cells(B, H, d->dtype) && cell_bwd_plan_ok(bd, op)) {
+    // large-tile cells (lstm_cell.hip); they leave the time sum of layer 0's gate gradients to one pass over the saved
+    // dgates.  (Tried: the batch rows as 2 / 4 independent launch chains on side streams, so that one chain's
+    // HBM-bound epilogue would run beside the other's contraction: 348 k / 312 k segments/s against 361 k for one chain.)
+    for (int64_t w = 0; w < T_ + L - 1; ++w) {
+      int nj = 0;
+      const BwdJobs<T> jobs = bwd_jobs<T>(bd, op, w, nj);
+      double fl = 0;
+      for (int j = 0; j < nj; ++j) fl += 2.0 * B * H * (jobs.job[j].seg[0].K + jobs.job[j].seg[1].K);
+      const int ts = trace_begin(st, kTraceBwdCell, fl);
+      const int e = launch_cell_bwd_big(jobs, nj, st);
+      trace_end(st, ts);
+      if (e) return e;
     }
+    if (Ic > 0) return launch_cell_dgsum((const T*)bd->dgates, bd->dgsum, (int)T_, B * 4 * H, st);
+    return FHVAE_OK;
   }
   for (int64_t w = 0; w < T_ + L - 1; ++w) {
     int nj = 0;

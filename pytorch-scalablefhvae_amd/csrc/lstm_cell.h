@@ -58,13 +58,19 @@ struct BwdJobs {
   BwdJob<T> job[FHVAE_MAX_LAYERS];
 };
 
-// Large-tile bf16 cells (lstm_cell.hip): every job's operands K-contiguous (a_kc = b_kc = 1), 16-byte aligned, K and the row
-// strides multiples of 64 / 8, B a multiple of 128, H a multiple of 64.  The predicates check one launch's jobs.
-bool cell_fwd_big_ok(const FwdJobs<u16>& jobs, int nj);
-bool cell_bwd_big_ok(const BwdJobs<u16>& jobs, int nj);
-int launch_cell_fwd_big(const FwdJobs<u16>& jobs, int nj, hipStream_t st);
-int launch_cell_bwd_big(const BwdJobs<u16>& jobs, int nj, hipStream_t st);  // ignores BwdJob::dgsum: launch_cell_dgsum after the loop
-// out[n] (f32) = sum over t of dg[t][n] (bf16), n = B * 4H a multiple of 8
-int launch_cell_dgsum(const u16* dg, float* out, int T, int64_t n, hipStream_t st);
+// Large-tile cells (lstm_cell.hip; T = u16: bf16 operands, T = float: exact-f32 MFMA): every job's operands K-contiguous
+// (a_kc = b_kc = 1), 16-byte aligned, K a multiple of 64 (bf16) / 32 (f32) -- layer-0 input segments: of 8 / 4 --, B a multiple
+// of 128, H of 64.  The predicates check one launch's jobs.
+template <typename T>
+bool cell_fwd_big_ok(const FwdJobs<T>& jobs, int nj);
+template <typename T>
+bool cell_bwd_big_ok(const BwdJobs<T>& jobs, int nj);
+template <typename T>
+int launch_cell_fwd_big(const FwdJobs<T>& jobs, int nj, hipStream_t st);
+template <typename T>
+int launch_cell_bwd_big(const BwdJobs<T>& jobs, int nj, hipStream_t st);  // ignores BwdJob::dgsum: launch_cell_dgsum after the loop
+// out[n] (f32) = sum over t of dg[t][n], n = B * 4H a multiple of 8
+template <typename T>
+int launch_cell_dgsum(const T* dg, float* out, int T_, int64_t n, hipStream_t st);
 
 }  // namespace fh

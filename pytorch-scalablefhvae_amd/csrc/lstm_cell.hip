@@ -26,15 +26,16 @@ struct CellSegs {
 // ---------------------------------------------------------------------------------------------
 // forward cell: 128 rows x 32 units (x 4 gates)
 // ---------------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel(FwdJobs<u16> jobs) {
+template <typename T, int NS>
+__global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel(FwdJobs<T> jobs) {
+  constexpr int BK = CellOp<T>::BK, EPC = CellOp<T>::EPC, ES = (int)sizeof(T);
   constexpr int BM = 128, RB = 128, UN = 32;
   constexpr int STAGE = (BM + RB) * 128;
   __shared__ __attribute__((aligned(1024))) char st0[STAGE];
   __shared__ __attribute__((aligned(1024))) char st1[STAGE];
   __shared__ __attribute__((aligned(1024))) char st2[NS > 2 ? STAGE : 16];
   __shared__ __attribute__((aligned(1024))) char st3[NS > 3 ? STAGE : 16];
-  const FwdJob<u16>& J = jobs.job[blockIdx.z];
+  const FwdJob<T>& J = jobs.job[blockIdx.z];
   const int H = jobs.H;
   const int m0 = blockIdx.x * BM, u0 = blockIdx.y * UN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -45,13 +46,13 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
   // (any K that is a multiple of 8: the 16-byte chunks past K are loaded from an out-of-range offset = zeros).  The segment
   // of a k-step is read from the kernel arguments by a dynamic (uniform) index: a select chain over four preloaded descriptors
   // became branches in the loop, and a branch there turns the counted vmcnt waits into vmcnt(0).
-  static_assert(offsetof(FwdJob<u16>, xseg) == offsetof(FwdJob<u16>, seg) + 2 * sizeof(Seg), "seg[] and xseg[] form one array of 4");
+  static_assert(offsetof(FwdJob<T>, xseg) == offsetof(FwdJob<T>, seg) + 2 * sizeof(Seg), "seg[] and xseg[] form one array of 4");
   const Seg* segs = &J.seg[0];
   int end0, end1, end2, end3;  // first k-step after each segment
-  end0 = (segs[0].K + kCellBK - 1) / kCellBK;
-  end1 = end0 + (segs[1].K + kCellBK - 1) / kCellBK;
-  end2 = end1 + (segs[2].K + kCellBK - 1) / kCellBK;
-  end3 = end2 + (segs[3].K + kCellBK - 1) / kCellBK;
+  end0 = (segs[0].K + BK - 1) / BK;
+  end1 = end0 + (segs[1].K + BK - 1) / BK;
+  end2 = end1 + (segs[2].K + BK - 1) / BK;
+  end3 = end2 + (segs[3].K + BK - 1) / BK;
   const int dbg = jobs.glds;  // FHVAE_CELL_DBG (timing ablations; wrong results): 1 no K loop, 2 no epilogue, 4 no stores
   const int nsteps = (dbg & 1) ? 0 : end3;
   // image row of this lane's piece q: (wave * 4 + q) * 8 + (lane >> 3); logical chunk c8 lands in physical chunk lane & 7.
@@ -74,14 +75,14 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
     start = ks >= end2 ? end2 : start;
     const int kl = ks - start;
     const Seg& S = segs[s];
-    const unsigned la = (unsigned)(S.lda * 2), lb = (unsigned)(S.ldb * 2);
-    const __amdgpu_buffer_rsrc_t a = __builtin_amdgcn_make_buffer_rsrc((u16*)S.A + (int64_t)m0 * S.lda, 0, (int)(BM * la), 0x00020000);
-    const __amdgpu_buffer_rsrc_t b = __builtin_amdgcn_make_buffer_rsrc((u16*)S.B, 0, (int)(4 * H * lb), 0x00020000);
+    const unsigned la = (unsigned)(S.lda * ES), lb = (unsigned)(S.ldb * ES);
+    const __amdgpu_buffer_rsrc_t a = __builtin_amdgcn_make_buffer_rsrc((T*)S.A + (int64_t)m0 * S.lda, 0, (int)(BM * la), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b = __builtin_amdgcn_make_buffer_rsrc((T*)S.B, 0, (int)(4 * H * lb), 0x00020000);
     // past the segment's K (or past the last step): bit 30 set = beyond num_records, the load returns zeros.  Plain ALU on
     // purpose: selects here came back as exec-masked branches inside the loop
     const int segK = S.K;
-    const unsigned oob = (unsigned)((int)(ks >= nsteps) | (int)(kl * kCellBK + (int)c8 * 8 >= segK)) << 30;
-    const unsigned kb = ((unsigned)(kl * (kCellBK * 2)) + c8 * 16u) | oob;
+    const unsigned oob = (unsigned)((int)(ks >= nsteps) | (int)(kl * BK + (int)c8 * EPC >= segK)) << 30;
+    const unsigned kb = ((unsigned)(kl * 128) + c8 * 16u) | oob;
     unsigned xa[4], xb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
     if (part != 1) cell_issue<4>(stg, a, xa, 0u, wave);
     if (part != 0) cell_issue<4>(stg + BM * 128, b, xb, 0u, wave);
   };
-  cell_mainloop<BM, RB, NS>(acc, nsteps, issue, st0, st1, st2, st3);
+  cell_mainloop<T, BM, RB, NS>(acc, nsteps, issue, st0, st1, st2, st3);
   if (dbg & 2) {
     if (acc[0][0][0] == 123.456f) J.c_out[0] = 0.f;
     return;
@@ -161,13 +162,13 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
     const unsigned o = row * uH + u;
     if ((dbg & 4) && c[0] != 123.456f) continue;
     st8(J.c_out + o, c);
-    st8_bf(J.h_out + o, h);
+    st8t(J.h_out + o, h);
     if (J.h_out_f32) st8(J.h_out_f32 + o, h);
-    u16* go = J.gates_out + row * 4u * uH + u;
-    st8_bf(go, ig);
-    st8_bf(go + uH, fg);
-    st8_bf(go + 2 * uH, gg);
-    st8_bf(go + 3 * uH, og);
+    T* go = J.gates_out + row * 4u * uH + u;
+    st8t(go, ig);
+    st8t(go + uH, fg);
+    st8t(go + 2 * uH, gg);
+    st8t(go + 3 * uH, og);
     if (J.hn_out) st8(J.hn_out + row * (unsigned)J.hn_ld + u, h);
   }
 }
@@ -175,15 +176,16 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
 // ---------------------------------------------------------------------------------------------
 // backward cell: BM (128 or 64) rows x 64 units
 // ---------------------------------------------------------------------------------------------
-template <int BM, int NS>
-__global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2 : 1) void cell_bwd_kernel(BwdJobs<u16> jobs) {
+template <typename T, int BM, int NS>
+__global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2 : 1) void cell_bwd_kernel(BwdJobs<T> jobs) {
   constexpr int BN = 64, TM = BM / 32, NIA = BM / 32;
+  constexpr int BK = CellOp<T>::BK, ES = (int)sizeof(T);
   constexpr int STAGE = (BM + BN) * 128;
   __shared__ __attribute__((aligned(1024))) char st0[STAGE];
   __shared__ __attribute__((aligned(1024))) char st1[STAGE];
   __shared__ __attribute__((aligned(1024))) char st2[NS > 2 ? STAGE : 16];
   __shared__ __attribute__((aligned(1024))) char st3[NS > 3 ? STAGE : 16];
-  const BwdJob<u16>& J = jobs.job[blockIdx.z];
+  const BwdJob<T>& J = jobs.job[blockIdx.z];
   const int H = jobs.H;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -196,21 +198,21 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
   for (int s = 0; s < 2; ++s) {
     const Seg& S = J.seg[s];
     const bool on = S.K > 0;
-    sg.a[s] = cell_rsrc(on ? (const u16*)S.A + (int64_t)((jobs.glds & 8) ? 0 : m0) * S.lda : nullptr, (int64_t)BM * S.lda * 2);
-    sg.b[s] = cell_rsrc(on ? (const u16*)S.B + (int64_t)((jobs.glds & 16) ? 0 : n0) * S.ldb : nullptr, (int64_t)BN * S.ldb * 2);
+    sg.a[s] = cell_rsrc(on ? (const T*)S.A + (int64_t)((jobs.glds & 8) ? 0 : m0) * S.lda : nullptr, (int64_t)BM * S.lda * ES);
+    sg.b[s] = cell_rsrc(on ? (const T*)S.B + (int64_t)((jobs.glds & 16) ? 0 : n0) * S.ldb : nullptr, (int64_t)BN * S.ldb * ES);
 #pragma unroll
     for (int q = 0; q < NIA; ++q) {
       const int row = (wave * NIA + q) * 8 + (lane >> 3);
-      va[s][q] = (unsigned)row * (unsigned)(S.lda * 2) + (unsigned)((lane & 7) ^ (row & 7)) * 16u;
+      va[s][q] = (unsigned)row * (unsigned)(S.lda * ES) + (unsigned)((lane & 7) ^ (row & 7)) * 16u;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int row = (wave * 2 + q) * 8 + (lane >> 3);
-      vb[s][q] = (unsigned)row * (unsigned)(S.ldb * 2) + (unsigned)((lane & 7) ^ (row & 7)) * 16u;
+      vb[s][q] = (unsigned)row * (unsigned)(S.ldb * ES) + (unsigned)((lane & 7) ^ (row & 7)) * 16u;
     }
   }
-  sg.n0 = J.seg[0].K / kCellBK;
-  sg.n = sg.n0 + J.seg[1].K / kCellBK;
+  sg.n0 = J.seg[0].K / BK;
+  sg.n = sg.n0 + J.seg[1].K / BK;
   const int dbg = jobs.glds;
   if (dbg & 1) sg.n = sg.n0 = 0;
 
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
 
   auto issue = [&](char* stg, int ks, int part) {
     const bool s1 = ks >= sg.n0;
-    const unsigned kb = ks < sg.n ? (unsigned)((s1 ? ks - sg.n0 : ks) * (kCellBK * 2)) : kCellOob;
+    const unsigned kb = ks < sg.n ? (unsigned)((s1 ? ks - sg.n0 : ks) * 128) : kCellOob;
     const __amdgpu_buffer_rsrc_t ra = s1 ? sg.a[1] : sg.a[0], rb = s1 ? sg.b[1] : sg.b[0];
     unsigned xa[NIA], xb[2];
 #pragma unroll
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
     if (part != 1) cell_issue<NIA>(stg, ra, xa, kb, wave);
     if (part != 0) cell_issue<2>(stg + BM * 128, rb, xb, kb, wave);
   };
-  cell_mainloop<BM, BN, NS>(acc, sg.n, issue, st0, st1, st2, st3);
+  cell_mainloop<T, BM, BN, NS>(acc, sg.n, issue, st0, st1, st2, st3);
   if (dbg & 2) {
     if (acc[0][0][0] == 123.456f) J.dc[0] = 0.f;
     return;
@@ -274,10 +276,10 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
     const unsigned row = m0 + wmk * (BM / 2) + lr;
     const unsigned o = row * uH + u, o4 = row * 4u * uH + u;
     float dh[8], ig[8], fg[8], gg[8], og[8], cp[8], cc[8], dcin[8], e1[8], e2[8];
-    unpack_bf8(*(const u32x4v*)(J.gates + o4), ig);
-    unpack_bf8(*(const u32x4v*)(J.gates + o4 + uH), fg);
-    unpack_bf8(*(const u32x4v*)(J.gates + o4 + 2 * uH), gg);
-    unpack_bf8(*(const u32x4v*)(J.gates + o4 + 3 * uH), og);
+    ld8t(J.gates + o4, ig);
+    ld8t(J.gates + o4 + uH, fg);
+    ld8t(J.gates + o4 + 2 * uH, gg);
+    ld8t(J.gates + o4 + 3 * uH, og);
     ld8(cprev + o, cp);
     ld8(J.c_cur + o, cc);
     ld8(J.dc + o, dcin);
@@ -311,47 +313,44 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
     if ((dbg & 4) && dcn[0] != 123.456f) continue;
     st8(J.dc + o, dcn);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) st8_bf(J.dg_out + o4 + g * uH, dp[g]);
+    for (int g = 0; g < 4; ++g) st8t(J.dg_out + o4 + g * uH, dp[g]);
   }
 }
 
-// sum over t of the saved bf16 gate gradients of layer 0 -> f32 [B,4H]: what the time-constant input's gradients contract with
-// (the generic cells keep this sum as a read-modify-write of 32 MB per step; one pass over the 168 MB of dgates is cheaper)
-__global__ __launch_bounds__(256) void cell_dgsum_kernel(const u16* __restrict__ dg, float* __restrict__ out, int T, int64_t n) {
+// sum over t of the saved gate gradients of layer 0 -> f32 [B,4H]: what the time-constant input's gradients contract with
+// (the generic cells keep this sum as a read-modify-write of 32 MB per step; one pass over the saved dgates is cheaper)
+template <typename T>
+__global__ __launch_bounds__(256) void cell_dgsum_kernel(const T* __restrict__ dg, float* __restrict__ out, int T_, int64_t n) {
   const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
   if (e >= n) return;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-  for (int t = 0; t < T; ++t) {
+  for (int t = 0; t < T_; ++t) {
     float v[8];
-    unpack_bf8(*(const u32x4v*)(dg + (int64_t)t * n + e), v);
+    ld8t(dg + (int64_t)t * n + e, v);
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] += v[k];
   }
   st8(out + e, acc);
 }
 
-template __global__ void cell_fwd_kernel<2>(FwdJobs<u16>);
-template __global__ void cell_fwd_kernel<3>(FwdJobs<u16>);
-template __global__ void cell_bwd_kernel<128, 3>(BwdJobs<u16>);
-template __global__ void cell_bwd_kernel<128, 4>(BwdJobs<u16>);
-template __global__ void cell_bwd_kernel<64, 3>(BwdJobs<u16>);
-template __global__ void cell_bwd_kernel<64, 4>(BwdJobs<u16>);
-
 static bool cell_misaligned(const void* p) { return (((uintptr_t)p) & 15) != 0; }
 
-static bool cell_seg_ok(const Seg& s, int64_t rows_a, int64_t rows_b, int kmult) {
+// es: bytes per operand element
+static bool cell_seg_ok(const Seg& s, int64_t rows_a, int64_t rows_b, int kmult, int es) {
   if (s.K == 0) return true;
-  if (!s.a_kc || !s.b_kc || s.a_rmod || (s.K % kmult) || (s.lda % 8) || (s.ldb % 8)) return false;
+  const int epc = 16 / es;
+  if (!s.a_kc || !s.b_kc || s.a_rmod || (s.K % kmult) || (s.lda % epc) || (s.ldb % epc)) return false;
   if ((((uintptr_t)s.A) | ((uintptr_t)s.B)) & 15) return false;
   // 32-bit buffer offsets below kCellOob
-  return rows_a * s.lda * 2 < (int64_t)kCellOob && rows_b * s.ldb * 2 < (int64_t)kCellOob;
+  return rows_a * s.lda * es < (int64_t)kCellOob && rows_b * s.ldb * es < (int64_t)kCellOob;
 }
 
-bool cell_fwd_big_ok(const FwdJobs<u16>& jobs, int nj) {
+template <typename T>
+bool cell_fwd_big_ok(const FwdJobs<T>& jobs, int nj) {
   if (jobs.B % 128 || jobs.H % 32 || (int64_t)jobs.B * 4 * jobs.H * 4 >= (1LL << 31)) return false;
   for (int j = 0; j < nj; ++j) {
-    const FwdJob<u16>& J = jobs.job[j];
+    const FwdJob<T>& J = jobs.job[j];
     if ((J.pre && J.pre_ld * jobs.B * 4 >= (1LL << 31)) || (J.hn_out && J.hn_ld * jobs.B * 4 >= (1LL << 31))) return false;
     // 16-byte epilogue accesses
     if ((J.pre && (J.pre_ld % 4)) || (J.hn_out && (J.hn_ld % 4))) return false;
@@ -361,16 +360,17 @@ bool cell_fwd_big_ok(const FwdJobs<u16>& jobs, int nj) {
   }
   for (int j = 0; j < nj; ++j)
     for (int s = 0; s < 2; ++s) {
-      if (!cell_seg_ok(jobs.job[j].seg[s], 128, 4 * (int64_t)jobs.H, kCellBK)) return false;
-      if (!cell_seg_ok(jobs.job[j].xseg[s], 128, 4 * (int64_t)jobs.H, 8)) return false;
+      if (!cell_seg_ok(jobs.job[j].seg[s], 128, 4 * (int64_t)jobs.H, CellOp<T>::BK, sizeof(T))) return false;
+      if (!cell_seg_ok(jobs.job[j].xseg[s], 128, 4 * (int64_t)jobs.H, CellOp<T>::EPC, sizeof(T))) return false;
     }
   return true;
 }
 
-bool cell_bwd_big_ok(const BwdJobs<u16>& jobs, int nj) {
+template <typename T>
+bool cell_bwd_big_ok(const BwdJobs<T>& jobs, int nj) {
   if (jobs.B % 128 || jobs.H % 64 || (int64_t)jobs.B * 4 * jobs.H * 4 >= (1LL << 31)) return false;
   for (int j = 0; j < nj; ++j) {
-    const BwdJob<u16>& J = jobs.job[j];
+    const BwdJob<T>& J = jobs.job[j];
     if ((J.ext && J.ext_ld * jobs.B * 4 >= (1LL << 31)) || (J.ext2 && J.ext2_ld * jobs.B * 4 >= (1LL << 31))) return false;
     if ((J.ext && (J.ext_ld % 4)) || (J.ext2 && (J.ext2_ld % 4))) return false;
     if (cell_misaligned(J.ext) || cell_misaligned(J.ext2) || cell_misaligned(J.gates) || cell_misaligned(J.c_prev) ||
@@ -379,45 +379,65 @@ bool cell_bwd_big_ok(const BwdJobs<u16>& jobs, int nj) {
   }
   for (int j = 0; j < nj; ++j)
     for (int s = 0; s < 2; ++s)
-      if (!cell_seg_ok(jobs.job[j].seg[s], 128, 64, kCellBK)) return false;
+      if (!cell_seg_ok(jobs.job[j].seg[s], 128, 64, CellOp<T>::BK, sizeof(T))) return false;
   return true;
 }
 
-int launch_cell_fwd_big(const FwdJobs<u16>& jobs, int nj, hipStream_t st) {
+template <typename T>
+int launch_cell_fwd_big(const FwdJobs<T>& jobs, int nj, hipStream_t st) {
   static const int ns = getenv("FHVAE_CELL_FWD_NS") ? atoi(getenv("FHVAE_CELL_FWD_NS")) : 2;
   static const int dbg = getenv("FHVAE_CELL_DBG") ? atoi(getenv("FHVAE_CELL_DBG")) : 0;
-  FwdJobs<u16> jd = jobs;
+  FwdJobs<T> jd = jobs;
   jd.glds = dbg;
   const dim3 grid((unsigned)(jobs.B / 128), (unsigned)(jobs.H / 32), (unsigned)nj), block(kCellThreads);
   if (ns == 3)
-    hipLaunchKernelGGL((cell_fwd_kernel<3>), grid, block, 0, st, jd);
+    hipLaunchKernelGGL((cell_fwd_kernel<T, 3>), grid, block, 0, st, jd);
   else
-    hipLaunchKernelGGL((cell_fwd_kernel<2>), grid, block, 0, st, jd);
+    hipLaunchKernelGGL((cell_fwd_kernel<T, 2>), grid, block, 0, st, jd);
   return fh_launch_status();
 }
 
-int launch_cell_bwd_big(const BwdJobs<u16>& jobs, int nj, hipStream_t st) {
+template <typename T>
+int launch_cell_bwd_big(const BwdJobs<T>& jobs, int nj, hipStream_t st) {
   static const int ns = getenv("FHVAE_CELL_BWD_NS") ? atoi(getenv("FHVAE_CELL_BWD_NS")) : 4;
   static const int bm = getenv("FHVAE_CELL_BWD_BM") ? atoi(getenv("FHVAE_CELL_BWD_BM")) : 64;
   static const int dbg = getenv("FHVAE_CELL_DBG") ? atoi(getenv("FHVAE_CELL_DBG")) : 0;
-  BwdJobs<u16> jd = jobs;
+  BwdJobs<T> jd = jobs;
   jd.glds = dbg;
   const dim3 grid((unsigned)(jobs.B / (bm == 128 ? 128 : 64)), (unsigned)(jobs.H / 64), (unsigned)nj), block(kCellThreads);
   if (bm == 128 && ns == 3)
-    hipLaunchKernelGGL((cell_bwd_kernel<128, 3>), grid, block, 0, st, jd);
+    hipLaunchKernelGGL((cell_bwd_kernel<T, 128, 3>), grid, block, 0, st, jd);
   else if (bm == 128)
-    hipLaunchKernelGGL((cell_bwd_kernel<128, 4>), grid, block, 0, st, jd);
+    hipLaunchKernelGGL((cell_bwd_kernel<T, 128, 4>), grid, block, 0, st, jd);
   else if (ns == 3)
-    hipLaunchKernelGGL((cell_bwd_kernel<64, 3>), grid, block, 0, st, jd);
+    hipLaunchKernelGGL((cell_bwd_kernel<T, 64, 3>), grid, block, 0, st, jd);
   else
-    hipLaunchKernelGGL((cell_bwd_kernel<64, 4>), grid, block, 0, st, jd);
+    hipLaunchKernelGGL((cell_bwd_kernel<T, 64, 4>), grid, block, 0, st, jd);
   return fh_launch_status();
 }
 
-int launch_cell_dgsum(const u16* dg, float* out, int T, int64_t n, hipStream_t st) {
+template <typename T>
+int launch_cell_dgsum(const T* dg, float* out, int T_, int64_t n, hipStream_t st) {
   if ((n % 8) || cell_misaligned(dg) || cell_misaligned(out)) return FHVAE_ERR_ALIGN;
-  hipLaunchKernelGGL(cell_dgsum_kernel, dim3((unsigned)fh_cdiv(n / 8, 256)), dim3(256), 0, st, dg, out, T, n);
+  hipLaunchKernelGGL(cell_dgsum_kernel<T>, dim3((unsigned)fh_cdiv(n / 8, 256)), dim3(256), 0, st, dg, out, T_, n);
   return fh_launch_status();
 }
+
+// explicit instantiations (the kernels' device stubs and the host entry points of both operand types)
+#define FH_CELL_INST(T)                                                    \
+  template __global__ void cell_fwd_kernel<T, 2>(FwdJobs<T>);             \
+  template __global__ void cell_fwd_kernel<T, 3>(FwdJobs<T>);             \
+  template __global__ void cell_bwd_kernel<T, 128, 3>(BwdJobs<T>);        \
+  template __global__ void cell_bwd_kernel<T, 128, 4>(BwdJobs<T>);        \
+  template __global__ void cell_bwd_kernel<T, 64, 3>(BwdJobs<T>);         \
+  template __global__ void cell_bwd_kernel<T, 64, 4>(BwdJobs<T>);         \
+  template __global__ void cell_dgsum_kernel<T>(const T*, float*, int, int64_t); \
+  template bool cell_fwd_big_ok<T>(const FwdJobs<T>&, int);               \
+  template bool cell_bwd_big_ok<T>(const BwdJobs<T>&, int);               \
+  template int launch_cell_fwd_big<T>(const FwdJobs<T>&, int, hipStream_t); \
+  template int launch_cell_bwd_big<T>(const BwdJobs<T>&, int, hipStream_t); \
+  template int launch_cell_dgsum<T>(const T*, float*, int, int64_t, hipStream_t);
+FH_CELL_INST(u16)
+FH_CELL_INST(float)
 
 }  // namespace fh

@@ -6,7 +6,29 @@
 namespace fh {
 
 constexpr int kCellThreads = 256;
-constexpr int kCellBK = 64;
+constexpr int kCellBK = 64;  // bf16 elements per stage row (128 B); f32: CellOp<float>::BK = 32
+
+// operand type of the cells: bf16 (v_mfma_f32_16x16x32_bf16: a 16-byte chunk = a lane's 8 k of one MFMA) or f32
+// (v_mfma_f32_16x16x4_f32, exact: a 16-byte chunk = 4 k, one per MFMA, the k order permuted identically for both operands)
+template <typename T>
+struct CellOp;
+template <>
+struct CellOp<u16> {
+  using Frag = bf16x8;
+  static constexpr int EPC = 8, BK = 64;
+  static __device__ __forceinline__ void mma(f32x4& acc, const Frag& a, const Frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+template <>
+struct CellOp<float> {
+  using Frag = f32x4;
+  static constexpr int EPC = 4, BK = 32;
+  static __device__ __forceinline__ void mma(f32x4& acc, const Frag& a, const Frag& b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+  }
+};
 constexpr unsigned kCellOob = 0x40000000u;  // beyond every descriptor's num_records: the load returns zeros
 
 typedef void __attribute__((address_space(3))) * cell_lds_p;
@@ -34,8 +56,9 @@ __device__ __forceinline__ void cell_issue(char* img, __amdgpu_buffer_rsrc_t rs,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cell_lds_p)(img + (wave * NI + q) * 1024), 16, voff[q] + kbytes, 0, 0, AUX);
 }
 
-__device__ __forceinline__ bf16x8 cell_frag(const char* img, int off) {
-  typedef bf16x8 __attribute__((address_space(3))) * lp;
+template <typename F>
+__device__ __forceinline__ F cell_frag(const char* img, int off) {
+  typedef F __attribute__((address_space(3))) * lp;
   return *(lp)(img + off);
 }
 
@@ -43,7 +66,7 @@ __device__ __forceinline__ bf16x8 cell_frag(const char* img, int off) {
 // TM x TN 16x16 tiles at A rows wm * RA/2 ..., B rows wn * RB/2 ....  `issue(stage, ks, part)` starts the DMA of k-step ks (zeros
 // past the last one): part 0 = the A pieces, 1 = the B pieces, 2 = both.  Step s: wait for this wave's pieces of stage s, barrier (all pieces landed; everybody is done with
 // stage s-1), refill stage s-1's buffer with step s+NS-1, multiply stage s.
-template <int RA, int RB, int NS, typename Issue>
+template <typename T, int RA, int RB, int NS, typename Issue>
 __device__ __forceinline__ void cell_mainloop(f32x4 (&acc)[RA / 32][RB / 32], int nsteps, Issue&& issue, char* s0, char* s1, char* s2, char* s3) {
   constexpr int TM = RA / 32, TN = RB / 32;
   constexpr int NLOAD = RA / 32 + RB / 32;
@@ -66,16 +89,17 @@ __device__ __forceinline__ void cell_mainloop(f32x4 (&acc)[RA / 32][RB / 32], in
     issue(nxt, ks_next, 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bf16x8 a[TM], b[TN];
+      using Frag = typename CellOp<T>::Frag;
+      Frag a[TM], b[TN];
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b[tn] = cell_frag(cur, offb + tn * 2048 + cj[j]);
+      for (int tn = 0; tn < TN; ++tn) b[tn] = cell_frag<Frag>(cur, offb + tn * 2048 + cj[j]);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) a[tm] = cell_frag(cur, offa + tm * 2048 + cj[j]);
+      for (int tm = 0; tm < TM; ++tm) a[tm] = cell_frag<Frag>(cur, offa + tm * 2048 + cj[j]);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        for (int tn = 0; tn < TN; ++tn) CellOp<T>::mma(acc[tm][tn], a[tm], b[tn]);
       __builtin_amdgcn_s_setprio(0);
     }
   };
@@ -113,5 +137,11 @@ __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
 __device__ __forceinline__ void st8_bf(u16* p, const float (&v)[8]) {
   *(u32x4v*)p = u32x4v{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
 }
+
+// 8 consecutive elements of the operand dtype <-> f32
+__device__ __forceinline__ void ld8t(const u16* p, float (&o)[8]) { unpack_bf8(*(const u32x4v*)p, o); }
+__device__ __forceinline__ void ld8t(const float* p, float (&o)[8]) { ld8(p, o); }
+__device__ __forceinline__ void st8t(u16* p, const float (&v)[8]) { st8_bf(p, v); }
+__device__ __forceinline__ void st8t(float* p, const float (&v)[8]) { st8(p, v); }
 
 }  // namespace fh

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kCellThreads, 2) void cell_fwd_stream_kernel(FwdStr
       if (part != 1) cell_issue<4, kStreamSc1>(stg, a, xa, 0u, wave);  // h of this launch (and x, xc): past the L1
       if (part != 0) cell_issue<4>(stg + BM * 128, b, xb, 0u, wave);
     };
-    cell_mainloop<BM, RB, NS>(acc, nsteps, issue, st0, st1, st2, st3);
+    cell_mainloop<u16, BM, RB, NS>(acc, nsteps, issue, st0, st1, st2, st3);
     ST_TLOG(t * 8 + 2);
 
     // epilogue through LDS (lstm_cell.hip): X[row][gate][32 units] f32, then (row, 8 units) items with 16-byte accesses
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kCellThreads, 2) void cell_bwd_stream_kernel(BwdStr
       if (part != 1) cell_issue<NIA, kStreamSc1>(stg, a, xa, 0u, wave);  // dgates of this launch: past the L1
       if (part != 0) cell_issue<2>(stg + BM * 128, b, xb, 0u, wave);
     };
-    cell_mainloop<BM, BN, NS>(acc, nsteps, issue, st0, st1, st2, st3);
+    cell_mainloop<u16, BM, BN, NS>(acc, nsteps, issue, st0, st1, st2, st3);
     ST_TLOG(s_ * 8 + 2);
 
     __syncthreads();

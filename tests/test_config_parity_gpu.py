@@ -121,6 +121,20 @@ def test_big_cells_h512_bf16_vs_torch_lstm_and_generic_cells(hb, monkeypatch, B,
             assert rel < 4e-3, (mode, k, rel)
 
 
+@pytest.mark.parametrize("B,T,I,Ic,H,L", [(256, 5, 80, 32, 256, 2), (128, 4, 0, 64, 256, 2), (256, 3, 80, 0, 512, 2), (128, 4, 80, 32, 256, 1)])
+def test_big_cells_f32_vs_torch_lstm(hb, monkeypatch, B, T, I, Ic, H, L):
+    """The large-tile cells with f32 operands (exact-f32 MFMA; what configs[4] runs at its batch), forced on at a batch the CPU
+    oracle handles: the parity-mode tolerance of the other f32 LSTM tests, 1e-4 of each tensor's max, forward and gradients."""
+    monkeypatch.setenv("FHVAE_BIG_CELLS", "1")
+    lstm, names, params, (out, hn_cat, xc), (hs_top, hnd, xcd) = _lstm_case(hb, B, T, I, Ic, H, L, "f32", seed=3 * B + I + H)
+    close(hs_top.transpose(0, 1), out, rtol=1e-4, what="hs_top")
+    close(hnd, hn_cat, rtol=1e-4, what="hn")
+    for p, n in zip(params, names):
+        close(p.grad, getattr(lstm, n).grad, rtol=1e-4, what="d" + n)
+    if Ic:
+        close(xcd.grad, xc.grad, rtol=1e-4, what="dxc")
+
+
 def test_simple_fhvae_z32_vs_oracle(hb):
     """configs[0]: SimpleFHVAE(1600, 128/128, z1 = z2 = 32), 250 segments, 100-row table: all six outputs element-wise at
     1e-4, the loss and every gradient (reference objective: decoder gradients are None) at 1e-4 of the tensor's max."""
