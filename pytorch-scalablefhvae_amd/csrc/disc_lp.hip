@@ -18,6 +18,8 @@
 // is bound by the exp / weight arithmetic on the VALU instead.
 #include "disc_mfma.h"
 
+#include <type_traits>
+
 namespace fh {
 
 namespace {
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
   __shared__ __attribute__((aligned(16))) float yn[kYT];
   __shared__ float ymax[kYT], yinv[kYT];
   __shared__ int ytgt[kYT];
+  __shared__ int yown[kYT / 32][4];  // !XQ: wave w staged a query of block b whose target is one of this workgroup's rows
   __shared__ float tr[MODE == 1 ? 256 : 1][MODE == 1 ? kD + 1 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
         xtgt[t] = (tg >= 0 && tg < a.NY) ? (int)tg : -1;
         if (MODE == 1) {
           xmax[t] = a.rmax[x];
-          xinv[t] = 1.f / a.rsum[x];
+          xinv[t] = gscale / a.rsum[x];  // (the upstream scale rides on the normaliser)
         }
       }
     } else {
@@ -156,20 +159,26 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
       nrm += __shfl_xor(nrm, 1, 64);
       nrm += __shfl_xor(nrm, 2, 64);
       nrm += __shfl_xor(nrm, 4, 64);
+      bool mine = false;  // (!XQ) this query's own row is among the workgroup's stationary rows
       if (c4 == 0) {
         yn[row] = nrm;
-        if (!XQ) {  // streamed queries: their (max, 1/sum, target)
+        if (!XQ) {  // streamed queries: their (max, scale/sum, target)
           const int y = y0 + row;
           const bool ok = y < y_end;
           ymax[row] = ok && MODE == 1 ? a.rmax[y] : 0.f;
-          yinv[row] = ok && MODE == 1 ? 1.f / a.rsum[y] : 0.f;
+          yinv[row] = ok && MODE == 1 ? gscale / a.rsum[y] : 0.f;
           int tg = -3;
           if (ok) {
             const int64_t vv = a.idx[y] - a.row0;
             tg = (vv >= 0 && vv < a.NX) ? (int)vv : -3;
           }
           ytgt[row] = tg;
+          mine = tg >= (int)blockIdx.y * 256 && tg < (int)blockIdx.y * 256 + 256;
         }
+      }
+      if (!XQ) {  // pass p stages the 32 rows of block p, 8 per wave
+        const bool any = __any(mine);
+        if (lane == 0) yown[p][wave] = any ? 1 : 0;
       }
     }
     __syncthreads();
@@ -210,9 +219,19 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
           tl[dj] = frag_t(ylo, yp * 32, dj, g, i);
         }
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      // Interior blocks with no (query, own row) pair -- all but ~2 % of them -- take the unmasked body: validity and own-row
+      // selects were a third of the loop's VALU work (58 v_cndmask + 59 compares + 64 s_and per 32-row block), and the loop is
+      // VALU-bound.  The test is wave-uniform: the block and this wave's 64 stationary vectors are whole, and none of the
+      // vectors' targets falls into the block (XQ) / no streamed query of the block has its target among the workgroup's rows.
+      const int yb = y0 + yp * 32;
+      const bool whole = yb + 32 <= y_end && x0 + 64 <= a.NX;
+      bool own_blk = false;
+      if (!XQ) own_blk = (yown[yp][0] | yown[yp][1] | yown[yp][2] | yown[yp][3]) != 0;
+      const float c2 = 2.f * a.c;
+      auto tile = [&](int t, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         const bool xok = x0 + t * 16 + i < a.NX;
+        const float cxn = a.c * xn[t];
         float w8[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -223,11 +242,14 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
           float lg[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int y = y0 + yp * 32 + h * 16 + 4 * g + r;
-            lg[r] = (xok && y < y_end) ? 2.f * a.c * acc[r] - a.c * (ynr[h][r] + xn[t]) : -INFINITY;
-            // the query's own row is handled exactly by the callers (disc_mfma.hip)
-            const bool own = (MODE == 1 && !XQ) ? ytg[h][r] == xtgt[t] : xtgt[t] == y;
-            if (own) lg[r] = -INFINITY;
+            lg[r] = c2 * acc[r] - (a.c * ynr[h][r] + cxn);
+            if constexpr (MASKED) {
+              const int y = yb + h * 16 + 4 * g + r;
+              if (!(xok && y < y_end)) lg[r] = -INFINITY;
+              // the query's own row is handled exactly by the callers (disc_mfma.hip)
+              const bool own = (MODE == 1 && !XQ) ? ytg[h][r] == xtgt[t] : xtgt[t] == y;
+              if (own) lg[r] = -INFINITY;
+            }
           }
           if constexpr (MODE == 0) {
             const float gm = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
@@ -235,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
               ssum[t] *= __expf(m[t] - gm);
               m[t] = gm;
             }
-            if (m[t] > -INFINITY) {
+            if (!MASKED || m[t] > -INFINITY) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) ssum[t] += __expf(lg[r] - m[t]);
             }
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
                 p = __expf(lg[r] - xmax[t]) * xinv[t];
               else
                 p = __expf(lg[r] - ymx[h][r]) * yiv[h][r];
-              w8[h * 4 + r] = (lg[r] > -INFINITY) ? gscale * p : 0.f;
+              w8[h * 4 + r] = (!MASKED || lg[r] > -INFINITY) ? p : 0.f;
             }
           }
         }
@@ -269,6 +291,15 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
             gacc[t][dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tl[dj], wb.v, gacc[t][dj], 0, 0, 0);
           }
         }
+      };
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bool masked = !whole || own_blk;
+        if (XQ) masked = masked || __any((unsigned)(xtgt[t] - yb) < 32u);
+        if (masked)
+          tile(t, std::true_type{});
+        else
+          tile(t, std::false_type{});
       }
     }
     __syncthreads();
