@@ -3,6 +3,8 @@ the kernels log wall_clock64() (100 MHz) at wait-begin / wait-end / contraction-
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch-scalablefhvae_amd"))
 os.environ["FHVAE_CLUSTER_TLOG"] = "1"
+os.environ["FHVAE_STREAM"] = "1"      # the persistent form is opt-in
+os.environ["FHVAE_BIG_CELLS"] = "1"   # (also below the batch the heuristic takes)
 import torch
 import hip_binding as hb
 
