@@ -348,3 +348,39 @@ def test_fused_loss_matches_expression(hb):
     close(loss, want, rtol=1e-5, what="loss")
     close(lb.grad, lb2.grad, rtol=1e-6, what="d_lb")
     close(qy.grad, qy2.grad, rtol=1e-6, what="d_qy")
+
+
+@pytest.mark.gpu
+def test_lstm_workspace_size_queries(hb):
+    """fhvae_lstm_pre_elems / fhvae_lstm_ws_below_elems / fhvae_lstm_lp_bytes per schedule: the (T,B,4H) `pre` buffer only where a
+    schedule reads it, `ws_below` only for the layer-by-layer persistent backward at H != 256, a workspace in f32 mode too."""
+    import ctypes as C
+
+    lib = hb.load_library()
+
+    def desc(dtype, L, B, T, I, Ic, H):
+        d = hb.LstmDesc()
+        params = []
+        for l in range(L):
+            kin = I + Ic if l == 0 else H
+            params += [torch.zeros(4 * H, kin, device="cuda"), torch.zeros(4 * H, H, device="cuda"), torch.zeros(4 * H, device="cuda"),
+                       torch.zeros(4 * H, device="cuda")]
+        hb._fill_lstm_desc(d, dtype, (L, B, T, I, Ic, H), None, None, params)
+        n = int(lib.fhvae_lstm_lp_bytes(C.byref(d)))
+        lp = torch.empty(max(n, 16), device="cuda", dtype=torch.uint8)
+        d.lp = lp.data_ptr()
+        return d, n, (params, lp)
+
+    T = 20
+    d, n, keep = desc(hb.BF16, 2, 2048, T, 80, 32, 256)  # persistent rows form, x folded into the kernel
+    assert n > 0 and lib.fhvae_lstm_pre_elems(C.byref(d)) == 2048 * 4 * 256 and lib.fhvae_lstm_ws_below_elems(C.byref(d)) == 0
+    d, n, keep = desc(hb.BF16, 2, 2048, T, 80, 0, 128)  # persistent, H = 128: the from-above term goes through ws_below
+    assert lib.fhvae_lstm_ws_below_elems(C.byref(d)) == T * 2048 * 128
+    d, n, keep = desc(hb.BF16, 2, 2048, T, 80, 32, 512)  # large-tile cells: they multiply layer 0's input themselves
+    assert lib.fhvae_lstm_pre_elems(C.byref(d)) == 1
+    d, n, keep = desc(hb.BF16, 2, 64, T, 80, 32, 512)  # generic per-step cells
+    assert lib.fhvae_lstm_pre_elems(C.byref(d)) == T * 64 * 4 * 512 and lib.fhvae_lstm_ws_below_elems(C.byref(d)) == 0
+    d, n, keep = desc(hb.F32, 2, 64, T, 80, 32, 256)  # f32: workspace = sync block + transposed weights
+    assert n == 16384 + 4 * (3 * 4 * 256 * 256) and lib.fhvae_lstm_pre_elems(C.byref(d)) == T * 64 * 4 * 256
+    d, n, keep = desc(hb.F32, 2, 64, T, 0, 64, 256)  # time-constant input only: one (B,4H) slab
+    assert lib.fhvae_lstm_pre_elems(C.byref(d)) == 64 * 4 * 256
