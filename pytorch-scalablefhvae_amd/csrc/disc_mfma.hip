@@ -17,6 +17,8 @@
 // registers (row = 4*(lane>>4)+r): exactly the B-operand layout of the second product, so w never leaves registers.
 #include "disc_mfma.h"
 
+#include <type_traits>
+
 namespace fh {
 
 
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
   __shared__ __attribute__((aligned(16))) float yn[YT];
   __shared__ float ymax[YT], yinv[YT];
   __shared__ int ytgt[YT];
+  __shared__ int yown[YT / 16];  // streamed queries: block b holds one whose own row is among this workgroup's stationary rows
   __shared__ float tr[MODE == 1 ? 256 : 1][MODE == 1 ? D + 1 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
         xtgt[t] = (tg >= 0 && tg < a.NY) ? (int)tg : -1;
         if (MODE == 1) {
           xmax[t] = a.rmax[x];
-          xinv[t] = 1.f / a.rsum[x];
+          xinv[t] = gscale / a.rsum[x];  // (the upstream scale rides on the normaliser)
         }
       }
     } else {
@@ -133,20 +136,26 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
       }
       nrm += __shfl_xor(nrm, 1, 64);
       nrm += __shfl_xor(nrm, 2, 64);
+      bool mine = false;
       if (part == 0) {
         yn[row] = nrm;
         const int y = y0 + row;
         if (!a.x_is_query) {
           const bool ok = y < y_end;
           ymax[row] = ok && MODE == 1 ? a.rmax[y] : 0.f;
-          yinv[row] = ok && MODE == 1 ? 1.f / a.rsum[y] : 0.f;
+          yinv[row] = ok && MODE == 1 ? gscale / a.rsum[y] : 0.f;  // (the upstream scale rides on the normaliser)
           int tg = -3;
           if (ok) {
             const int64_t v = a.idx[y] - a.row0;
             tg = (v >= 0 && v < a.NX) ? (int)v : -3;
           }
           ytgt[row] = tg;
+          mine = tg >= (int)blockIdx.y * 256 && tg < (int)blockIdx.y * 256 + 256;
         }
+      }
+      {  // wave w holds the 16 rows of block w
+        const bool any = __any(mine);
+        if (lane == 0) yown[wave] = any ? 1 : 0;
       }
     }
     __syncthreads();
@@ -170,8 +179,13 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
           ytg[r] = ytgt[yb * 16 + 4 * g + r];
         }
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      // interior blocks without a (query, own row) pair take the body without the validity / own-row selects (disc_lp.hip)
+      const int ybase = y0 + yb * 16;
+      const bool whole = ybase + 16 <= y_end && x0 + 64 <= a.NX;
+      const bool own_blk = !a.x_is_query && yown[yb] != 0;
+      const float c2 = 2.f * a.c;
+      auto tile = [&](int t, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
@@ -182,14 +196,18 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua.w), __uint_as_float(ub.w), acc, 0, 0, 0);
         }
         const bool xok = x0 + t * 16 + i < a.NX;
+        const float cxn = a.c * xn[t];
         float lg[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int y = y0 + yb * 16 + 4 * g + r;
-          lg[r] = (xok && y < y_end) ? 2.f * a.c * acc[r] - a.c * (ynr[r] + xn[t]) : -INFINITY;
-          // the query's own row is handled exactly by the callers (see the note above the kernel)
-          const bool own = (MODE == 1 && !a.x_is_query) ? ytg[r] == xtgt[t] : xtgt[t] == y;
-          if (own) lg[r] = -INFINITY;
+          lg[r] = c2 * acc[r] - (a.c * ynr[r] + cxn);
+          if constexpr (MASKED) {
+            const int y = ybase + 4 * g + r;
+            if (!(xok && y < y_end)) lg[r] = -INFINITY;
+            // the query's own row is handled exactly by the callers (see the note above the kernel)
+            const bool own = (MODE == 1 && !a.x_is_query) ? ytg[r] == xtgt[t] : xtgt[t] == y;
+            if (own) lg[r] = -INFINITY;
+          }
         }
         if constexpr (MODE == 0) {
           const float gm = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
@@ -197,7 +215,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
             ssum[t] *= __expf(m[t] - gm);
             m[t] = gm;
           }
-          if (m[t] > -INFINITY) {
+          if (!MASKED || m[t] > -INFINITY) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) ssum[t] += __expf(lg[r] - m[t]);
           }
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
               p = __expf(lg[r] - xmax[t]) * xinv[t];
             else
               p = __expf(lg[r] - ymx[r]) * yiv[r];
-            w[r] = (lg[r] > -INFINITY) ? gscale * p : 0.f;  // (own pairs: masked above, added by disc_own_bwd_kernel)
+            w[r] = (!MASKED || lg[r] > -INFINITY) ? p : 0.f;  // (own pairs: masked above, added by disc_own_bwd_kernel)
             wsum[t] += w[r];
           }
           // G^T[d][x] += sum_y Y[y][d] * w[y][x]: A = Y^T from LDS (lane: d = 16*dj + i, y = 4g + r), B = w[r]
@@ -224,6 +242,15 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
             }
           }
         }
+      };
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bool masked = !whole || own_blk;
+        if (a.x_is_query) masked = masked || __any((unsigned)(xtgt[t] - ybase) < 16u);
+        if (masked)
+          tile(t, std::true_type{});
+        else
+          tile(t, std::false_type{});
       }
     }
     __syncthreads();
