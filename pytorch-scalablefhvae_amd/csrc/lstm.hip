@@ -884,7 +884,11 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
       }
     }
     if (!(sizeof(T) == 2 && cluster_eligible(d))) {  // (the persistent backward kernels sum the bias gradients themselves)
-      e = launch_colsum(dgl, d->dtype, G, bd->db_ih[l], bd->db_hh[l], T_ * B, G, st);
+      // layer 0 with a time-constant input: the sum over t already exists (dgsum, f32 [B,4H]): B rows instead of T*B
+      if (l == 0 && Ic > 0 && bd->dgsum)
+        e = launch_colsum(bd->dgsum, FHVAE_F32, G, bd->db_ih[l], bd->db_hh[l], B, G, st);
+      else
+        e = launch_colsum(dgl, d->dtype, G, bd->db_ih[l], bd->db_hh[l], T_ * B, G, st);
       if (e) return e;
     }
   }
