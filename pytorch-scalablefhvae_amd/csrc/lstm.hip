@@ -476,7 +476,7 @@ static StreamWeights stream_weights(const Ops<u16>& op) {
   for (int l = 0; l < FHVAE_MAX_LAYERS; ++l) w.w_ih[l] = op.w_ih[l], w.w_hh[l] = op.w_hh[l], w.w_ih_t[l] = op.w_ih_t[l], w.w_hh_t[l] = op.w_hh_t[l];
   return w;
 }
-static StreamWeights stream_weights(const Ops<float>&) { return StreamWeights{}; }
+[[maybe_unused]] static StreamWeights stream_weights(const Ops<float>&) { return StreamWeights{}; }
 
 // the forward jobs of wavefront step w; `big`: for the large-tile cells, which multiply layer 0's input themselves (no `pre`)
 template <typename T>
