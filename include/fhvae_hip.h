@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 5
+#define FHVAE_ABI_VERSION 6
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -199,6 +199,14 @@ int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* descs, int n,
  * FHVAE_ERR_ALIGN when the preconditions do not hold. */
 int fhvae_wgrad_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc, int64_t M,
                      int64_t N, int64_t K, void* stream);
+
+/* c[M,N] (f32, ldc) = a[M,K] . b[N,K]^T (+ bias[N], may be NULL): bf16 operands with the contraction index CONTIGUOUS in both
+ * (lda, ldb in elements, multiples of 8; K % 64 == 0, N % 4 == 0; 16-byte aligned bases; M*lda*2 < 2^31) -- an activation matrix
+ * over M = batch x time rows times a weight matrix as nn.Linear / nn.LSTM store it (y = x W^T, simple_fhvae.py:130; for the LSTM
+ * body missing at fhvae.py:14: the from-above term dh^l += dgates^{l+1} . W_ih^{l+1} of the backward, for all time steps at
+ * once).  One tile per CU, every row of `a` read once (csrc/proj.hip).  FHVAE_ERR_ALIGN when the preconditions do not hold. */
+int fhvae_proj_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const float* bias, float* c, int64_t ldc,
+                    int64_t M, int64_t N, int64_t K, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * mu2 gather (K4): mu2[b,:] = table[idx[b],:]  -- torch.gather, simple_fhvae.py:53.

@@ -365,7 +365,12 @@ static LpLayout lp_layout(const fhvae_lstm_desc* d) {
     o.w_ih_t[l] = take(l == 0 ? 0 : 4 * d->H * kin);
     o.w_hh_t[l] = take(4 * d->H * d->H);
   }
-  o.xch = take(2 * (int64_t)d->L * d->B * 4 * d->H);  // the persistent kernels' exchange buffer (lstm_cluster.hip)
+  {  // the persistent kernels' exchange buffer: blocked copies of h / dg (lstm_cluster.hip, xch_off) or the partial-dh slots of
+     // the per-layer backward at H = 256 (lstm_bwd_rs.hip: a fixed kRsXchElems whatever the batch)
+    int64_t cnt = 2 * (int64_t)d->L * d->B * 4 * d->H;
+    if (d->H == 256 && cnt < fh::kRsXchElems) cnt = fh::kRsXchElems;
+    o.xch = take(cnt);
+  }
   o.total = n;
   return o;
 }

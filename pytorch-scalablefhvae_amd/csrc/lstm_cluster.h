@@ -19,6 +19,10 @@ constexpr int kSyncWordsUsed = 3072;  // the words the operand cast re-arms: the
 // the same sequence from the same zeroed block).
 constexpr int kSeqEpochs = 4096;
 
+// bf16 elements of the exchange buffer the partial-dh backward (lstm_bwd_rs.hip) needs: 2 parities x 64 clusters x 4 sources x
+// 3 destinations x 4 waves x 2 row tiles x 1 KB
+constexpr int64_t kRsXchElems = 2LL * 64 * 4 * 3 * 4 * 2 * 512;
+
 struct ClusterWeights {  // bf16 operand copies in the workspace
   const u16* w_ih[FHVAE_MAX_LAYERS];    // [4H, H]   (l >= 1)
   const u16* w_hh[FHVAE_MAX_LAYERS];    // [4H, H]

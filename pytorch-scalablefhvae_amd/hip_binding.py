@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
 
 F32, BF16 = 0, 1
 MAX_LAYERS = 4
-ABI_VERSION = 5  # FHVAE_ABI_VERSION of include/fhvae_hip.h
+ABI_VERSION = 6  # FHVAE_ABI_VERSION of include/fhvae_hip.h
 #: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
 INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
@@ -93,6 +93,7 @@ SIGNATURES = {
     "fhvae_lstm_seq_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), _vp]),
     "fhvae_lstm_param_grads_multi": (C.c_int, [C.POINTER(C.POINTER(LstmBwdDesc)), C.c_int, _vp]),
     "fhvae_wgrad_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "fhvae_proj_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     "fhvae_mu2_gather_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp]),
     "fhvae_disc_lse_rescale": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
@@ -944,6 +945,20 @@ def wgrad_bf16_(c, a, b):
     with _Timed("fhvae_wgrad_bf16"):
         _check(lib.fhvae_wgrad_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), M, N, K, _stream()), "fhvae_wgrad_bf16")
     return c
+
+
+def proj_bf16(a, w, bias=None, out=None):
+    """out[M,N] (f32) = a[M,K] . w[N,K]^T (+ bias) for bf16 a, w with contiguous rows (fhvae_proj_bf16: csrc/proj.hip)."""
+    lib = load_library()
+    _need_gpu(a, w)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    with _Timed("fhvae_proj_bf16"):
+        _check(lib.fhvae_proj_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, _stream()), "fhvae_proj_bf16")
+    return out
 
 
 def adam_step_(p, g, m, v, step_dev, lr, beta1, beta2, eps, grad_scale=1.0, p_lp=None):

@@ -146,6 +146,31 @@ def test_wgrad_bf16_vs_cpu_matmul(hb, K, M, N):
     assert (cd.cpu().double() - want2).abs().max().item() <= 4e-5 * K ** 0.5 + 1e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(40960, 256, 1024), (40960, 160, 256), (2048, 64, 512), (1000, 256, 64), (300, 96, 128), (17, 4, 64),
+                                   (5000, 512, 320)])
+def test_proj_bf16_vs_cpu_matmul(hb, M, N, K):
+    """fhvae_proj_bf16: C = A B^T (+ bias) with K-contiguous bf16 operands (csrc/proj.hip: one row tile per CU, LDS-DMA double
+    buffer, swizzled ds_read_b128 fragments), ragged M / N, two column tiles, padded leading dimensions, against the f64 CPU
+    matmul of the same bf16 operands.  f32 accumulation in a different order: 2e-5 of the output's scale sqrt(K)."""
+    torch.manual_seed(M + N)
+    lda, ldb = K + (8 if M % 2 else 0), K + (16 if N % 3 == 0 else 0)
+    a_full, b_full = torch.randn(M, lda).bfloat16(), torch.randn(N, ldb).bfloat16()
+    a, b = a_full[:, :K], b_full[:, :K]
+    bias = torch.randn(N) if M % 3 else None
+    want = a.double() @ b.double().t() + (bias.double() if bias is not None else 0.0)
+    out = torch.full((M, N + 4), 7.0, device="cuda")  # a column range of a wider matrix: the pad must stay untouched
+    got = hb.proj_bf16(dev(a_full)[:, :K], dev(b_full)[:, :K], dev(bias) if bias is not None else None, out=out[:, :N])
+    err = (got.cpu().double() - want).abs().max().item()
+    assert err <= 2e-5 * K ** 0.5 + 1e-6, (err, K)
+    assert (out[:, N:] == 7.0).all()
+
+
+def test_proj_bf16_rejects_unaligned(hb):
+    a, b = torch.zeros(64, 72, device="cuda").bfloat16(), torch.zeros(8, 72, device="cuda").bfloat16()
+    with pytest.raises(RuntimeError):
+        hb.proj_bf16(a, b)  # K = 72 is not a multiple of 64
+
+
 def test_deferred_param_grads_match_immediate(hb):
     """With gradient sinks (FusedAdam) the nets' parameter gradients are queued and flushed as one grouped call by the
     optimizer: same gradients as the immediate path (FHVAE_NO_DEFER semantics via set_defer_param_grads(False))."""
@@ -373,7 +398,7 @@ def test_lstm_workspace_size_queries(hb):
 
     T = 20
     d, n, keep = desc(hb.BF16, 2, 2048, T, 80, 32, 256)  # persistent rows form, x folded into the kernel
-    assert n > 0 and lib.fhvae_lstm_pre_elems(C.byref(d)) == 2048 * 4 * 256 and lib.fhvae_lstm_ws_below_elems(C.byref(d)) == 0
+    assert n > 0 and lib.fhvae_lstm_pre_elems(C.byref(d)) == 2048 * 4 * 256 and lib.fhvae_lstm_ws_below_elems(C.byref(d)) == T * 2048 * 256
     d, n, keep = desc(hb.BF16, 2, 2048, T, 80, 0, 128)  # persistent, H = 128: the from-above term goes through ws_below
     assert lib.fhvae_lstm_ws_below_elems(C.byref(d)) == T * 2048 * 128
     d, n, keep = desc(hb.BF16, 2, 2048, T, 80, 32, 512)  # large-tile cells: they multiply layer 0's input themselves

@@ -1,0 +1,50 @@
+#!/bin/bash
+# Round-3 evidence for profiles/: run on the GPU box (bash tools/collect_r03.sh [what...]); outputs under gpurun_out/r03/.
+#   stats   rocprofv3 --kernel-trace per-kernel totals of the default bench (c3, B=2048, bf16) and of c2 B=256, c4, c5
+#   pmc     separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MfmaUtil) of the default bench -> pmc_traffic.json
+#   bench   the bench lines themselves (default, c4, c5, zipf)
+set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/r03
+mkdir -p $O
+WHAT=${@:-stats bench}
+cd /tmp && export TMPDIR=/tmp
+PROF="--no-cpu-baseline --no-roofline --no-alt --no-graph --steps 10 --warmup 3"
+stats() {  # name, bench args
+  local n=$1; shift
+  rm -rf /tmp/kt_$n
+  rocprofv3 --kernel-trace -d /tmp/kt_$n -o r -- python3 $R/bench.py $PROF "$@" > $O/prof_$n.log 2>&1
+  db=$(find /tmp/kt_$n -name "*.db" | head -1)
+  { echo "# rocprofv3 --kernel-trace -- python3 bench.py $PROF $* (per-kernel totals via tools/rocpd_stats.py; 13 steps traced, times per step)"; python3 $R/tools/rocpd_stats.py $db 13; } > $O/${n}_kernel_stats.txt
+  echo stats $n done
+}
+for w in $WHAT; do
+  case $w in
+    stats)
+      stats c3_bf16_B2048
+      stats c2_bf16_B256 --config c2 --batch 256
+      stats c4 --config c4
+      stats c5 --config c5
+      ;;
+    bench)
+      python3 $R/bench.py > $O/bench_default_c3.json 2> $O/bench_default_c3.log
+      python3 $R/bench.py --config c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.log
+      python3 $R/bench.py --config c5 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.log
+      python3 $R/bench.py --idx zipf --no-cpu-baseline --no-alt > $O/bench_c3_zipf.json 2> $O/bench_c3_zipf.log
+      python3 $R/bench.py --config c1 --no-cpu-baseline > $O/bench_c1.json 2> $O/bench_c1.log
+      echo bench done
+      ;;
+    pmc)
+      ARGS="--no-graph --no-roofline --no-cpu-baseline --no-alt --steps 6 --warmup 2"
+      rm -rf /tmp/pmc_fetch /tmp/pmc_write /tmp/pmc_mfma
+      rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch -- python3 $R/bench.py $ARGS > $O/pmc_fetch.log 2>&1
+      rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write -- python3 $R/bench.py $ARGS > $O/pmc_write.log 2>&1
+      python3 $R/tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write bf16 2048 > $O/pmc_traffic.txt 2>&1
+      cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json
+      rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d /tmp/pmc_mfma -- python3 $R/bench.py $ARGS > $O/pmc_mfma.log 2>&1
+      python3 $R/tools/pmc_quick.py /tmp/pmc_mfma > $O/pmc_mfma_util.txt 2>&1 || true
+      python3 $R/tools/pmc_quick.py /tmp/pmc_fetch /tmp/pmc_write > $O/pmc_fetch_write_top.txt 2>&1 || true
+      echo pmc done
+      ;;
+  esac
+done
