@@ -16,7 +16,6 @@
 #include "gemm_launch.h"
 #include "lstm_cell.h"
 #include "lstm_cluster.h"
-#include "lstm_stream.h"
 #include "wgrad.h"
 #include <algorithm>
 #include <vector>
@@ -475,14 +474,6 @@ static bool big_cells(int64_t B, int64_t H, int dtype = FHVAE_BF16) {
   return (B / 128) * (H / 64) >= (dtype == FHVAE_F32 ? 64 : 96);
 }
 
-static StreamWeights stream_weights(const Ops<u16>& op) {
-  StreamWeights w = {};
-  w.x = op.x, w.xc = op.xc;
-  for (int l = 0; l < FHVAE_MAX_LAYERS; ++l) w.w_ih[l] = op.w_ih[l], w.w_hh[l] = op.w_hh[l], w.w_ih_t[l] = op.w_ih_t[l], w.w_hh_t[l] = op.w_hh_t[l];
-  return w;
-}
-[[maybe_unused]] static StreamWeights stream_weights(const Ops<float>&) { return StreamWeights{}; }
-
 // the forward jobs of wavefront step w; `big`: for the large-tile cells, which multiply layer 0's input themselves (no `pre`)
 template <typename T>
 static FwdJobs<T> fwd_jobs(const fhvae_lstm_desc* d, const Ops<T>& op, int64_t w, bool big, int& nj) {
@@ -561,9 +552,7 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     xc_in = cluster && cluster_xc_in_kernel(d);
   }
   // large-tile step cells (lstm_cell.hip; all steps of the sequence or none): they multiply layer 0's input themselves
-  bool cell_big = false, stream = false;
-  if constexpr (sizeof(T) == 2) stream = !cluster && big_cells(B, H) && stream_eligible(d);  // ... as one persistent launch (lstm_stream.hip)
-  cell_big = stream || (!cluster && big_cells(B, H, d->dtype) && cell_fwd_plan_ok(d, op));
+  const bool cell_big = !cluster && big_cells(B, H, d->dtype) && cell_fwd_plan_ok(d, op);
   // fhvae_lstm_pre_elems has promised the caller that `pre` is not needed for this shape
   if (!cluster && !cell_big && big_cells(B, H, d->dtype) && big_shape_ok(d)) return FHVAE_ERR_ALIGN;
   if (!cell_big && !(fold && Ic == 0) && !xc_in) {
@@ -592,7 +581,6 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     }
   }
   if constexpr (sizeof(T) == 2) {
-    if (stream) return stream_fwd(d, stream_weights(op), st);
   }
   {
     if (cell_big) {  // large-tile cells (lstm_cell.hip)
@@ -757,12 +745,6 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
       cw.xch = (u16*)d->lp + lp_layout(d).xch;
       return cluster_bwd(bd, cw, st);
     }
-    if (big_cells(B, H) && stream_eligible(d)) {  // the forward took the same form (same predicate)
-      const int e = stream_bwd(bd, stream_weights(op), st);
-      if (e) return e;
-      if (Ic > 0) return launch_cell_dgsum((const u16*)bd->dgates, bd->dgsum, (int)T_, B * 4 * H, st);
-      return FHVAE_OK;
-    }
   }
   if (big_cells(B, H, d->dtype) && cell_bwd_plan_ok(bd, op)) {
     // large-tile cells (lstm_cell.hip); they leave the time sum of layer 0's gate gradients to one pass over the saved
@@ -832,18 +814,14 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
   // (at small batches each is a latency-bound launch of a few workgroups)
   GemmParams grp[2 * FHVAE_MAX_LAYERS];
   int ng = 0;
-  // the persistent backward may have left dgates in the blocked layout (cluster_dg_blocked): only wgrad.hip reads that
-  const bool dg_blocked = sizeof(T) == 2 && wq && cluster_dg_blocked(bd);
-  bool blocked_unread = false;
   // -> true: taken by the dedicated long-K kernel (queued in wq)
   auto wgrad_long = [&](const void* a, int64_t lda, const void* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc, int64_t Ncols) {
-    if (!wq || sizeof(T) != 2 || (!dg_blocked && Kc < kWgradMinK)) return false;
+    if (!wq || sizeof(T) != 2 || Kc < kWgradMinK) return false;
     WgProblem w = {};
     w.A = (const u16*)a, w.B = (const u16*)b, w.C = c;
     w.lda = lda, w.ldb = ldb, w.ldc = ldc;
     w.M = (int)G, w.N = (int)Ncols, w.K = (int)Kc;
-    w.a_blk_rows = dg_blocked ? (int)B : 0;
-    if (!wgrad_eligible(w)) return dg_blocked ? (blocked_unread = true, false) : false;
+    if (!wgrad_eligible(w)) return false;
     wq->push_back(w);
     return true;
   };
@@ -897,7 +875,6 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
       if (e) return e;
     }
   }
-  if (blocked_unread) return FHVAE_ERR_ALIGN;  // (cannot happen: cluster_dg_blocked implies wgrad's preconditions)
   return flush();
 }
 

@@ -9,8 +9,7 @@ constexpr int kSyncStatus = 0;    // 0 = ok; bit 0: a bounded spin gave up, bit 
 constexpr int kSyncSticky = 2;    // two words: address of fhvae_lstm_desc.sticky_status (0 = none), written when the block is armed
 constexpr int kSyncXcdCnt = 16;   // 8 arrival counters (one per XCD): ticket & 31 = a workgroup's slot on its XCD, ticket >> 5 = the launch
 constexpr int kSyncFlags = 64;    // + cluster * 32: one word per workgroup of the cluster = the last step it has published
-constexpr int kSyncWordsUsed = 3072;  // the words the operand cast re-arms: the cluster kernels' flags end at kSyncFlags + 64 * 32; the
-                                      // streaming cells (lstm_stream.hip) keep their placement counters behind their flags; the last
+constexpr int kSyncWordsUsed = 3072;  // the words the operand cast re-arms: the cluster kernels' flags end at kSyncFlags + 64 * 32; the last
                                       // quarter of the block (from byte 12288) is the phase-clock log of the profiling tools
 // The block is zeroed once per forward (by the operand-cast launch that precedes every bf16 forward); the launches that then
 // share it -- forward chunks, later the backward's, however often it runs -- number themselves: every launch takes 32 tickets
@@ -42,8 +41,6 @@ bool cluster_can_fold(const fhvae_lstm_desc* d);
 bool cluster_xc_in_kernel(const fhvae_lstm_desc* d);
 // the recurrence of fhvae_lstm_seq_fwd after the layer-0 input projection (d->pre filled): all T steps, all layers
 int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st);
-// bd->dgates is (to be) written in the blocked layout [l][t][4H/32][B][32] instead of row-major (L,T,B,4H)
-bool cluster_dg_blocked(const fhvae_lstm_bwd_desc* bd);
 // the backward needs fhvae_lstm_bwd_desc.ws_below
 bool cluster_needs_ws_below(const fhvae_lstm_desc* d);
 // the recurrence of fhvae_lstm_seq_bwd: fills dgates (and dgsum when Ic > 0)

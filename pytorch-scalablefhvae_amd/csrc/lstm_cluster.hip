@@ -25,7 +25,6 @@
 //   lstm_bwd_layer_kernel     backward of ONE layer per launch, 32 units per member (a quarter of the wavefront kernel's
 //                             exchange bytes per step), a helper wave fetching the epilogue operands; the from-above term
 //                             is a GEMM between the two launches (cluster_bwd_layers)
-//   lstm_bwd_cluster_kernel   backward as one wavefront (FHVAE_NO_LAYERWISE=1; superseded at these shapes)
 //   lstm_fwd/bwd_ksplit_kernel  <= 32 rows per cluster (B <= 512): the waves split the CONTRACTION, operands go
 //                             global -> registers from a blocked exchange buffer, partial tiles are summed through LDS
 //
@@ -524,240 +523,6 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
     // issue and ~1.5 us ahead of the h stores (201 against 190, with the cl_goff layout): a wave whose store queue is full
     // stalls its MFMAs too.  Fewer, fuller stores are what helps (the gate layout, cl_goff).
     tail_stores(s);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// backward: dh^l_t = dg^l_{t+1} . W_hh[l] + dg^{l+1}_t . W_ih[l+1] (+ external), elementwise LSTM backward -> dg^l_t.
-// Same decomposition: member `me` owns hidden units [16 me, 16 me + 16) of every layer; its 16 rows of W_hh[l]^T and of
-// W_ih[l+1]^T (K = 4H) live in LDS; dc and the running sum of dg live in registers.  What the members exchange per step
-// is dg^l of the previous step (bf16, fresh address per (l,t)): the matrix dg^l_{tau} is at once the recurrent operand
-// of layer l (time tau-1) and the from-above operand of layer l-1 (time tau), so it is staged once.
-// ---------------------------------------------------------------------------------------------
-
-template <int H, int L, int RB>
-struct ClBwdCfg {
-  static constexpr int GC = 4 * H / 8;                    // 16-byte chunks per dg row
-  static constexpr int TM = RB >= 64 ? RB / 64 : 1;
-  static constexpr int WR = TM * 16;
-  static constexpr int PCH = kPanel / (WR * 16);
-  static constexpr int NPP = GC / PCH;
-  static constexpr int KB = GC / 64;                      // weight slices are kept as KB blocks of [16 rows][64 chunks]
-  static constexpr int W_BYTES = 16 * GC * 16;
-  static constexpr int NW = 2 * L - 1;
-  static constexpr int SMEM = NW * W_BYTES + 4 * kRing * kPanel;
-  static_assert(GC % 64 == 0 && GC % PCH == 0 && PCH >= 8, "panel shape");
-};
-
-
-template <int H, int L, int RB>
-__global__ __launch_bounds__(kThreads) void lstm_bwd_cluster_kernel(ClBwd p) {
-  using CF = ClBwdCfg<H, L, RB>;
-  constexpr int TM = CF::TM, PCH = CF::PCH, NPP = CF::NPP, KB = CF::KB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Wl = smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  char* ring = smem + CF::NW * CF::W_BYTES + wave * (kRing * kPanel);  // this wave's staging ring
-  const int r = lane & 15, q = lane >> 4;
-
-  const int joined = cluster_join(p.sync, (int*)(smem + CF::NW * CF::W_BYTES));  // (the rings are idle until step 1)
-  if (joined < 0) return;
-  const int info = joined & 255;                                 // XCD * 32 + slot
-  const unsigned ep0 = (unsigned)(joined >> 8) * kSeqEpochs;     // this launch's number on the sync block
-  const int NU = p.NU;
-  const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
-  const int r0 = p.row0 + cluster * p.Mc;
-  const int rend = min(p.row0 + p.nrows, r0 + p.Mc);
-  if (r0 >= rend) return;
-  unsigned* flags = p.sync + kSyncFlags + cluster * 32;
-  const int u0 = me * 16, uq = u0 + q * 4;
-  const int B = p.B, T = p.T;
-  constexpr int G = 4 * H;
-
-  // ---- this member's 16 rows of every transposed weight -> LDS, once: slot 2l = W_hh[l]^T, slot 2l-1 = W_ih[l]^T
-  {
-    ClUnitMap um{u0};
-#pragma unroll
-    for (int l = 0; l < L; ++l)
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        glds_tile<u16, 16, 64>(Wl + (2 * l) * CF::W_BYTES + kb * 16384, p.w_hh_t[l], G, 0, kb * 512, um, 0, tid);
-        if (l > 0) glds_tile<u16, 16, 64>(Wl + (2 * l - 1) * CF::W_BYTES + kb * 16384, p.w_ih_t[l], G, 0, kb * 512, um, 0, tid);
-      }
-  }
-  const int wrow0 = wave * (TM * 16);
-  const bool wact = wrow0 < RB;
-  f32x4 dcreg[L][TM], ccur[L][TM], dgs[L][TM][4];  // dgs: running sums over t of dg (layer 0: also the d_xc operand)
-#pragma unroll
-  for (int l = 0; l < L; ++l)
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) dcreg[l][tm] = ccur[l][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int l = 0; l < L; ++l) dgs[l][tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  ClRowMap arm{r0, rend - 1};
-  auto pack4 = [](const f32x4& v) -> uint2 {
-    return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
-  };
-  unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
-
-  // epilogue operands of step `sn`: layer l handles t = T-1 - (sn - (L-1-l))
-  uint2 gk[L][TM][4];
-  f32x4 cprev[L][TM], ext[L][TM];
-  auto load_epi = [&](int sn) {
-    if (!wact) return;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const int t = T - 1 - (sn - (L - 1 - l));
-      if (t < 0 || t >= T) continue;
-      const int64_t lt = (int64_t)l * T + t;
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int row0_ = r0 + wrow0 + tm * 16 + r;
-        const int64_t row = row0_ < rend ? row0_ : rend - 1;
-        cl_load_gates(p.gates + (lt * B + row) * G, uq, gk[l][tm]);
-        if (t == T - 1) ccur[l][tm] = *(const f32x4*)(p.cs + (lt * B + row) * H + uq);
-        cprev[l][tm] = t > 0 ? *(const f32x4*)(p.cs + ((lt - 1) * B + row) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (l == L - 1 && p.d_hs_top) e = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + row) * H + uq);
-        if (t == T - 1 && p.d_hn) e += *(const f32x4*)(p.d_hn + row * p.hn_ld + l * H + uq);
-        ext[l][tm] = e;
-      }
-    }
-  };
-  const int nsteps = T + L - 1;
-  for (int s = 0; s < nsteps; ++s) {
-    CL_TLOG(s * 8 + 0);
-    // (1) the saved activations / cell states / external gradients of this step's (layer, time) pairs: independent of
-    //     the exchange, fetched under the wait.  (Fetching them one step ahead, under the previous epilogue, was measured
-    //     slower: 404 -> 448 us per net at B = 2048.)
-    load_epi(s);
-    // (2) dg of step s-1 from every member
-    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
-    CL_TLOG(s * 8 + 1);
-
-    // (3) contraction.  Source l = dg^l at tau_l = T - s + (L-1-l), valid for 0 <= tau_l <= T-1 (s >= 1).
-    f32x4 acc[L][TM];
-#pragma unroll
-    for (int l = 0; l < L; ++l)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) acc[l][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // tau_l <= T-1  <=>  l >= L - s;   tau_l >= 0  <=>  l <= T - s + L - 1: a contiguous range of layers
-    const int lo = L - s > 0 ? L - s : 0;
-    const int hi = T - s + L - 1 < L - 1 ? T - s + L - 1 : L - 1;
-    const int npan = hi >= lo ? (hi - lo + 1) * NPP : 0;
-    auto issue = [&](int n) {
-      const int l = lo + n / NPP, pp = n % NPP;
-      const int tau = T - s + (L - 1 - l);
-      const u16* src = p.dg + ((int64_t)(l * T + tau) * B) * G;
-      glds_wave_panel<CF::WR, PCH>(ring + (n % kRing) * kPanel, src, G, pp * PCH * 8, arm, wrow0, lane);
-    };
-    if (wact) {
-      for (int n = 0; n < kRing - 1 && n < npan; ++n) issue(n);
-      for (int n = 0; n < npan; ++n) {
-        wait_panels(npan - 1 - n < kRing - 2 ? npan - 1 - n : kRing - 2);
-        if (n + kRing - 1 < npan) issue(n + kRing - 1);
-        const int l = lo + n / NPP, pp = n % NPP;
-        const char* As = ring + (n % kRing) * kPanel;
-#pragma unroll
-        for (int ll = 0; ll < L; ++ll) {
-          if (ll != l) continue;
-          const bool rec = T - s + (L - 1 - ll) - 1 >= 0;  // layer ll itself is active (t = tau - 1 >= 0)
-          const char* Whh = Wl + (2 * ll) * CF::W_BYTES;
-          const char* Wih = Wl + (ll > 0 ? 2 * ll - 1 : 0) * CF::W_BYTES;  // W_ih[ll]^T: consumed by layer ll-1
-#pragma unroll
-          for (int j = 0; j < PCH / 4; ++j) {
-            bf16x8 a[TM];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-              a[tm] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + kc_off<PCH>(tm * 16 + r, (j << 2) | q)));
-            const int kc = pp * PCH + ((j << 2) | q);
-            const int woff = (kc >> 6) * 16384 + kc_off<64>(r, kc & 63);
-            if (rec) {
-              const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Whh + woff));
-#pragma unroll
-              for (int tm = 0; tm < TM; ++tm) acc[ll][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[ll][tm], 0, 0, 0);
-            }
-            if (ll > 0) {
-              const int ld = ll > 0 ? ll - 1 : 0;
-              const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(Wih + woff));
-#pragma unroll
-              for (int tm = 0; tm < TM; ++tm) acc[ld][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[tm], acc[ld][tm], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-    CL_TLOG(s * 8 + 2);
-
-    // (4) elementwise LSTM backward -> dg^l_t (what the other members wait for)
-    if (wact) {
-#pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const int t = T - 1 - (s - (L - 1 - l));
-        if (t < 0 || t >= T) continue;
-        const int64_t lt = (int64_t)l * T + t;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const int row = r0 + wrow0 + tm * 16 + r;
-          const f32x4 ig = unpack4(gk[l][tm][0]), fg = unpack4(gk[l][tm][1]), gg = unpack4(gk[l][tm][2]), og = unpack4(gk[l][tm][3]);
-          const f32x4 dh = acc[l][tm] + ext[l][tm];
-          f32x4 dp[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float tc = tanhf_(ccur[l][tm][i]);
-            float dc = dh[i] * og[i] * (1.f - tc * tc);
-            if (t != T - 1) dc += dcreg[l][tm][i];
-            const float d_o = dh[i] * tc;
-            const float d_i = dc * gg[i], d_f = dc * cprev[l][tm][i], d_g = dc * ig[i];
-            dcreg[l][tm][i] = dc * fg[i];
-            dp[0][i] = d_i * ig[i] * (1.f - ig[i]);
-            dp[1][i] = d_f * fg[i] * (1.f - fg[i]);
-            dp[2][i] = d_g * (1.f - gg[i] * gg[i]);
-            dp[3][i] = d_o * og[i] * (1.f - og[i]);
-          }
-          ccur[l][tm] = cprev[l][tm];  // c_{t-1} is the next step's c_t
-          if (row < rend) {  // (padding rows computed from clamped loads must not reach the sums)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dgs[l][tm][g] += dp[g];
-          }
-          if (row < rend) {
-            u16* go = p.dg + (lt * B + row) * G + uq;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *(uint2*)(go + g * H) = pack4(dp[g]);
-          }
-        }
-      }
-    }
-    CL_TLOG(s * 8 + 3);
-    // (5) publish
-    if (s + 1 < nsteps) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));
-    CL_TLOG(s * 8 + 4);
-  }
-  if (p.dgsum && wact) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int row = r0 + wrow0 + tm * 16 + r;
-      if (row >= rend) continue;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) *(f32x4*)(p.dgsum + (int64_t)row * G + g * H + uq) = dgs[0][tm][g];
-    }
-  }
-  if (wact) {
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      if (!p.db_ih[l] && !p.db_hh[l]) continue;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v = dgs[l][0][g];
-#pragma unroll
-        for (int tm = 1; tm < TM; ++tm) v += dgs[l][tm][g];
-        db_reduce_add(v, p.db_ih[l], p.db_hh[l], g * H + uq, lane);
-      }
-    }
   }
 }
 
@@ -1459,295 +1224,6 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, one layer per launch, CONTRACTION-SPLIT form (H = 256, at most 32 rows per cluster = 2048 rows per launch):
-// a member owns 64 units (its W_hh^T slice: 128 KB of LDS), so a cluster has only H/64 = 4 members and a step's exchange is
-// 32 rows x 4H x 2 B = 64 KB per CU (the 32-unit kernel above: 128 KB, the wavefront kernel: 512 KB).  The four waves split K:
-// wave kp loads its quarter of the k-steps for all rows straight into registers (blocked exchange buffer: a fragment is 1 KB
-// contiguous), the partial tiles are summed through LDS, wave w finishes unit tile w.  Epilogue operands are fetched one step
-// ahead (as in lstm_bwd_ksplit_kernel).
-// ---------------------------------------------------------------------------------------------
-// ABOVE (a layer below the top): the from-above term dg^{l+1}_t . W_ih[l+1] is computed HERE, from the finished layer above
-// (row-major dg, fetched a step ahead) against W_ih[l+1]^T held in the 128 KB of LDS this kernel no longer needs for its own
-// weights.  It is a K-split partial sum over the same unit tiles as the recurrent product, so it simply starts the accumulators
-// -- and it does not depend on the exchange, so its 64 MFMAs per wave run while the exchange loads are in flight.  The
-// (T*B x 4H x H) GEMM between the two launches of a net and its f32 (T,B,H) round trip are gone.
-// BLK: the gate gradients are SAVED in the blocked form [t][k-step][batch row][32] (the layout of the exchange buffer, one slot
-// per time step, in the dgates buffer itself) instead of row-major: the saved copy leaves straight from the registers behind
-// the publish (no LDS image, and with ABOVE no barrier protecting that image), the from-above operand of the layer below is read
-// as 1-KB fragments instead of 16 x 64 B at the row stride, and the weight-gradient kernel (wgrad.hip, WgProblem::a_blk_rows)
-// takes its A operand from the blocked layout.
-template <int H, int RT, bool ABOVE, bool BLK>
-__global__ __launch_bounds__(kThreads) void lstm_bwd_layer_ks_kernel(ClBwd p) {
-  constexpr int HU = 64, UT = 4;
-  constexpr int G = 4 * H, GC = G / 8, KB = GC / 64, KS = G / 32, KPW = KS / 4;
-  constexpr int WU_BYTES = ABOVE ? HU * GC * 16 : 0;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Wu = smem;                                    // ABOVE: this member's 64 rows of W_ih[l+1]^T
-  char* Part = smem + WU_BYTES;                       // [wave][RT][UT] tiles of 1 KB
-  char* Stg = smem + WU_BYTES + 4 * RT * UT * 1024;   // !ABOVE: dg of this step, [RT * 16 rows][4 gates][64 units] bf16
-  constexpr int kStgRow = 4 * HU * 2 + 16;
-  // ABOVE: no LDS is left for that image; wave w keeps its 32 bytes per (row, gate) in the partial tiles only IT reads (k = 0, 1
-  // of unit tile w), written after it has read them; a barrier in front of the next step's partial-tile writes protects it
-  auto stg_alias = [&](int wsrc, int rt, int row16, int g, int byte) -> char* {
-    const int off = (row16 * 4 + g) * 32 + byte;  // 2 KB per (wave, row tile)
-    return Part + (((off >> 10) * RT + rt) * UT + wsrc) * 1024 + (off & 1023);
-  };
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int kp = wave;
-
-  const int joined = cluster_join(p.sync, (int*)Part);
-  if (joined < 0) return;
-  const int info = joined & 255;                                 // XCD * 32 + slot
-  const unsigned ep0 = (unsigned)(joined >> 8) * kSeqEpochs;     // this launch's number on the sync block
-  const int NU = p.NU;
-  const int cluster = (info >> 5) * (32 / NU) + (info & 31) / NU, me = (info & 31) % NU;
-  const int r0 = p.row0 + cluster * p.Mc;
-  const int rend = min(p.row0 + p.nrows, r0 + p.Mc);
-  if (r0 >= rend) return;
-  unsigned* flags = p.sync + kSyncFlags + cluster * 32;
-  const int u0 = me * HU;
-  const int uq = u0 + wave * 16 + q * 4;  // epilogue: wave w finishes unit tile w of every row tile
-  const int B = p.B, T = p.T;
-  // wave kp multiplies the same KPW k-steps of W_hh^T against every step's dg: its 32 weight fragments (128 registers) are
-  // loaded ONCE and stay in registers -- the contraction reads no LDS at all
-  bf16x8 wreg[KPW][UT];
-#pragma unroll
-  for (int j = 0; j < KPW; ++j)
-#pragma unroll
-    for (int ut = 0; ut < UT; ++ut)
-      wreg[j][ut] = __builtin_bit_cast(bf16x8, *(const uint4*)(p.w_hh_t[0] + (int64_t)(u0 + ut * 16 + r) * G + ((((kp * KPW + j) << 2) | q) << 3)));
-  if constexpr (ABOVE) {
-    ClUnitMap um{u0};
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) glds_tile<u16, HU, 64>(Wu + kb * (HU * 1024), p.w_above_t, G, 0, kb * 512, um, 0, tid);
-  }
-  int row[RT];
-  int64_t rowc[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    row[rt] = r0 + rt * 16 + r;
-    rowc[rt] = row[rt] < rend ? row[rt] : rend - 1;
-  }
-  f32x4 dcreg[RT], ccur[RT], dgs[RT][4];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    dcreg[rt] = ccur[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < 4; ++g) dgs[rt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  auto pack4 = [](const f32x4& v) -> uint2 {
-    return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
-  };
-  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(p.xch);
-  unsigned long long* tl = (p.tlog && cluster == 0 && me == 0) ? p.tlog : nullptr;
-  __syncthreads();  // weights have landed (and every thread has read the join word)
-
-  uint2 gkn[RT][4];
-  f32x4 cprevn[RT], extn[RT], ccurn[RT];
-  auto load_epi = [&](int sn) {
-    const int t = T - 1 - sn;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      cl_load_gates(p.gates + ((int64_t)t * B + rowc[rt]) * G, uq, gkn[rt]);
-      if (sn == 0) ccurn[rt] = *(const f32x4*)(p.cs + ((int64_t)t * B + rowc[rt]) * H + uq);
-      cprevn[rt] = t > 0 ? *(const f32x4*)(p.cs + ((int64_t)(t - 1) * B + rowc[rt]) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.d_hs_top) e = *(const f32x4*)(p.d_hs_top + ((int64_t)t * B + rowc[rt]) * H + uq);
-      if (sn == 0 && p.d_hn) e += *(const f32x4*)(p.d_hn + rowc[rt] * p.hn_ld + uq);
-      extn[rt] = e;
-    }
-  };
-  load_epi(0);
-  // ABOVE: this wave's k-steps of dg^{l+1}_t (row-major), fetched one step ahead like the epilogue operands
-  uint4 a2n[RT][ABOVE ? KPW : 1];
-  auto load_above = [&](int t) {
-    if constexpr (ABOVE) {
-      const int tc = t > 0 ? t : 0;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        if constexpr (BLK) {  // blocked dg of the layer above: k-step ks of row r at ((t * KS + ks) * B + r) * 32
-          const u16* src = p.dg_above + (((int64_t)tc * KS + kp * KPW) * B + rowc[rt]) * 32 + q * 8;
-#pragma unroll
-          for (int j = 0; j < KPW; ++j) a2n[rt][j] = *(const uint4*)(src + (int64_t)j * B * 32);
-        } else {
-          const u16* src = p.dg_above + ((int64_t)tc * B + rowc[rt]) * G + (((kp * KPW) << 2) | q) * 8;
-#pragma unroll
-          for (int j = 0; j < KPW; ++j) a2n[rt][j] = *(const uint4*)(src + j * 32);
-        }
-      }
-    }
-  };
-  load_above(T - 1);
-  for (int s = 0; s < T; ++s) {
-    CL_TLOG(s * 8 + 0);
-    const int t = T - 1 - s;
-    uint2 gk[RT][4], dpk[RT][4];
-    f32x4 cprev[RT], ext[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gk[rt][g] = gkn[rt][g];
-      cprev[rt] = cprevn[rt];
-      ext[rt] = extn[rt];
-      if (s == 0) ccur[rt] = ccurn[rt];
-    }
-    f32x4 acc[RT][UT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int ut = 0; ut < UT; ++ut) acc[rt][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the from-above term of time t (it does not depend on the exchange): issued right behind the exchange loads, so that its
-    // 64 MFMAs per wave run while those loads are in flight
-    auto above_term = [&]() {
-      if constexpr (ABOVE) {
-      bf16x8 wu[2][UT];
-      auto ufrags = [&](int j, int buf) {
-        const int kc = ((kp * KPW + j) << 2) | q;
-#pragma unroll
-        for (int ut = 0; ut < UT; ++ut)
-          wu[buf][ut] = __builtin_bit_cast(bf16x8, *(const uint4*)(Wu + (kc >> 6) * (HU * 1024) + kc_off<64>(ut * 16 + r, kc & 63)));
-      };
-      ufrags(0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, UT, 0);
-#pragma unroll
-      for (int j = 0; j < KPW; ++j) {
-        if (j + 1 < KPW) ufrags(j + 1, (j + 1) & 1);
-#pragma unroll
-        for (int ut = 0; ut < UT; ++ut)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[j & 1][ut], __builtin_bit_cast(bf16x8, a2n[rt][j]), acc[rt][ut], 0, 0, 0);
-        if (j + 1 < KPW) {  // the next k-step's four fragment reads go out behind this one's first MFMA
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, UT, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, RT * UT - 1, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, RT * UT, 0);
-        }
-      }
-    }
-    };
-    if (s > 0 && !cluster_wait(p.sync, flags, NU, ep0 + (unsigned)s)) return;
-    CL_TLOG(s * 8 + 1);
-    if (s > 0) {
-      uint4 a[RT][KPW];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int64_t base = (xch_off((s - 1) & 1, 0, 1, KS, kp * KPW, B, rowc[rt]) + q * 8) * 2;
-#pragma unroll
-        for (int j = 0; j < KPW; ++j) a[rt][j] = load_sc1(dg_rs, base + j * (B * 64));
-      }
-      __builtin_amdgcn_sched_barrier(0);  // every exchange load is in flight before the first MFMA (the scheduler sinks them otherwise)
-      above_term();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < KPW; ++j)
-#pragma unroll
-        for (int ut = 0; ut < UT; ++ut)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            acc[rt][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][ut], __builtin_bit_cast(bf16x8, a[rt][j]), acc[rt][ut], 0, 0, 0);
-    } else {
-      above_term();
-    }
-    if constexpr (ABOVE) {
-      __builtin_amdgcn_sched_barrier(0);
-      load_above(t - 1);  // behind the exchange loads and their MFMAs: lands during the epilogue
-    }
-    if constexpr (ABOVE && !BLK) __syncthreads();  // every wave has read the dg image of the previous step out of the partial tiles
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int ut = 0; ut < UT; ++ut) *(f32x4*)(Part + ((wave * RT + rt) * UT + ut) * 1024 + lane * 16) = acc[rt][ut];
-    if (s + 1 < T) load_epi(s + 1);
-    __syncthreads();
-    CL_TLOG(s * 8 + 2);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      f32x4 dh = ext[rt];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dh += *(const f32x4*)(Part + ((k * RT + rt) * UT + wave) * 1024 + lane * 16);
-      const f32x4 ig = unpack4(gk[rt][0]), fg = unpack4(gk[rt][1]), gg = unpack4(gk[rt][2]), og = unpack4(gk[rt][3]);
-      f32x4 dp[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float tc = tanhf_(ccur[rt][i]);
-        float dc = dh[i] * og[i] * (1.f - tc * tc);
-        if (s > 0) dc += dcreg[rt][i];
-        const float d_o = dh[i] * tc;
-        const float d_i = dc * gg[i], d_f = dc * cprev[rt][i], d_g = dc * ig[i];
-        dcreg[rt][i] = dc * fg[i];
-        dp[0][i] = d_i * ig[i] * (1.f - ig[i]);
-        dp[1][i] = d_f * fg[i] * (1.f - fg[i]);
-        dp[2][i] = d_g * (1.f - gg[i] * gg[i]);
-        dp[3][i] = d_o * og[i] * (1.f - og[i]);
-      }
-      ccur[rt] = cprev[rt];
-      if (row[rt] < rend) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          dgs[rt][g] += dp[g];
-          dpk[rt][g] = pack4(dp[g]);
-          *(uint2*)(p.xch + xch_off(s & 1, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];  // what the members wait for
-          if constexpr (!BLK) {
-            if constexpr (ABOVE)
-              *(uint2*)stg_alias(wave, rt, r, g, q * 8) = dpk[rt][g];
-            else
-              *(uint2*)(Stg + (rt * 16 + r) * kStgRow + g * (HU * 2) + (wave * 16 + q * 4) * 2) = dpk[rt][g];
-          }
-        }
-      }
-    }
-    CL_TLOG(s * 8 + 3);
-    if (s + 1 < T) cluster_publish(flags, me, ep0 + (unsigned)(s + 1));  // (its barrier also frees Part)
-    else __syncthreads();
-    CL_TLOG(s * 8 + 4);
-    // BLK: the saved copy is the same blocked image, in slot t of the dgates buffer, stored from the registers behind the
-    // publish (the exchange itself stays in the two L2-hot parity slots: with the exchange in per-step slots the top layer's
-    // launch took 124 us against 108)
-    if constexpr (BLK) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        if (row[rt] < rend) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *(uint2*)(p.dg + xch_off(t, 0, 1, KS, (g * H + uq) >> 5, B, row[rt]) + (uq & 31)) = dpk[rt][g];
-        }
-    }
-    // the row-major copy the weight-gradient contractions read leaves through the LDS image as whole 128-byte lines (a lane's
-    // own values are 8-byte pieces of 16 different lines per instruction)
-    if constexpr (!BLK) {
-      uint4 v[RT * 2];
-#pragma unroll
-      for (int i = 0; i < RT * 2; ++i) {
-        const int c = (wave * RT * 2 + i) * 64 + lane, idx = c >> 3;  // 16-byte chunk c of the image: (row, gate) idx, chunk c & 7
-        if constexpr (ABOVE)
-          v[i] = *(const uint4*)stg_alias((c & 7) >> 1, idx >> 6, (idx >> 2) & 15, idx & 3, (c & 1) * 16);
-        else
-          v[i] = *(const uint4*)(Stg + (idx >> 2) * kStgRow + (idx & 3) * (HU * 2) + (c & 7) * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < RT * 2; ++i) {
-        const int c = (wave * RT * 2 + i) * 64 + lane, idx = c >> 3;
-        const int rw = r0 + (idx >> 2);
-        if (rw < rend) *(uint4*)(p.dg + ((int64_t)t * B + rw) * G + (idx & 3) * H + u0 + (c & 7) * 8) = v[i];
-      }
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      v += dgs[rt][g];
-      if (p.dgsum && row[rt] < rend) *(f32x4*)(p.dgsum + (int64_t)row[rt] * G + g * H + uq) = dgs[rt][g];
-    }
-    if (p.db_ih[0] || p.db_hh[0]) db_reduce_add(v, p.db_ih[0], p.db_hh[0], g * H + uq, lane);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static bool device_ok() {
@@ -1898,19 +1374,6 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
 }
 
 template <int H, int L, int RB>
-static int launch_bwd_rb(const ClBwd& p, hipStream_t st) {
-  using CF = ClBwdCfg<H, L, RB>;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_cluster_kernel<H, L, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  hipLaunchKernelGGL((lstm_bwd_cluster_kernel<H, L, RB>), dim3(kGrid), dim3(kThreads), CF::SMEM, st, p);
-  return fh_launch_status();
-}
-
-template <int H, int L, int RB>
 static int launch_bwd_ks(const ClBwd& p, hipStream_t st) {
   constexpr int SMEM = (2 * L - 1) * 16 * (4 * H / 8) * 16 + 4 * L * 1024 + 16;
   static bool attr = false;
@@ -1925,12 +1388,7 @@ static int launch_bwd_ks(const ClBwd& p, hipStream_t st) {
 
 template <int H, int L>
 static int launch_bwd(const ClBwd& p, int RB, hipStream_t st) {
-  switch (RB) {
-    case 16: return launch_bwd_ks<H, L, 16>(p, st);
-    case 32: return launch_bwd_ks<H, L, 32>(p, st);
-    case 64: return launch_bwd_rb<H, L, 64>(p, st);
-    default: return launch_bwd_rb<H, L, 128>(p, st);
-  }
+  return RB <= 16 ? launch_bwd_ks<H, L, 16>(p, st) : launch_bwd_ks<H, L, 32>(p, st);
 }
 
 template <int H, int RB>
@@ -1962,60 +1420,42 @@ static int launch_bwd_layer_rb(const ClBwd& p, int RB, hipStream_t st) {
   }
 }
 
-template <int RT, bool ABOVE, bool BLK>
-static int launch_bwd_layer_ks_a(const ClBwd& p, hipStream_t st) {
-  constexpr int SMEM = ABOVE ? 64 * (4 * 256 / 8) * 16 + 4 * RT * 4 * 1024 : 4 * RT * 4 * 1024 + RT * 16 * (4 * 64 * 2 + 16);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_layer_ks_kernel<256, RT, ABOVE, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  hipLaunchKernelGGL((lstm_bwd_layer_ks_kernel<256, RT, ABOVE, BLK>), dim3(kGrid), dim3(kThreads), SMEM, st, p);
-  return fh_launch_status();
-}
-template <int RT>
-static int launch_bwd_layer_ks(const ClBwd& p, bool blk, hipStream_t st) {
-  if (blk) return p.dg_above ? launch_bwd_layer_ks_a<RT, true, true>(p, st) : launch_bwd_layer_ks_a<RT, false, true>(p, st);
-  return p.dg_above ? launch_bwd_layer_ks_a<RT, true, false>(p, st) : launch_bwd_layer_ks_a<RT, false, false>(p, st);
+
+// H = 256, rows form: the per-layer backward exchanges partial dh (lstm_bwd_rs.hip)
+static bool cluster_bwd_rs(const fhvae_lstm_desc* d) {
+  return cluster_eligible(d) && cluster_form(d) == 1 && d->H == 256 && !getenv("FHVAE_NO_RS");
 }
 
-// Whether the backward of this net keeps its gate gradients only in the blocked layout (lstm_bwd_layer_ks_kernel<.., BLK>): the
-// per-layer contraction-split kernels with the fused from-above term run (H = 256, rows form), every time slot is a whole number
-// of 64-row wgrad k-steps, and the weight gradients go through wgrad.hip (which reads that layout).  Both phases of
-// fhvae_lstm_seq_bwd evaluate this: the layout of bd->dgates follows from the descriptor alone.
-bool cluster_dg_blocked(const fhvae_lstm_bwd_desc* bd) {
-  const fhvae_lstm_desc* d = &bd->f;
-  if (!cluster_eligible(d) || cluster_form(d) != 1 || d->H != 256) return false;
-  if (getenv("FHVAE_NO_LAYERWISE") || getenv("FHVAE_NO_LAYER_KS") || getenv("FHVAE_NO_FUSE_ABOVE")) return false;
-  // opt-in: measured (c3, B = 2048, interleaved A/B on one device) 930-933 k segments/s with it against 942-945 k without --
-  // the 8-byte stores of the blocked copy cost more than the LDS image + whole-line stores of the row-major copy save
-  if (getenv("FHVAE_NO_WGRAD") || !getenv("FHVAE_DG_BLOCKED") || !getenv("FHVAE_NO_RS")) return false;
-  if (d->B % 64 != 0 || d->T < 2 || d->I % 8 != 0) return false;
-  if ((int64_t)d->T * d->B * 4 * d->H * 2 >= (1LL << 30)) return false;  // wgrad's 32-bit buffer offsets
-  return true;
-}
-
-static bool cluster_bwd_rs(const fhvae_lstm_desc* d);
-
-// rows form, layer by layer (see lstm_bwd_layer_kernel): top layer first, then the from-above contraction as one GEMM into
-// bd->ws_below, then the layer below with that as its external gradient
+// rows form, layer by layer: the top layer's recurrence as one persistent launch, then for every layer below the from-above term
+// dg^{l+1} . W_ih[l+1] of ALL steps as one GEMM into bd->ws_below (it is not recurrent), then that layer's launch with it as the
+// external gradient.  H = 256: 64 units per member, partial-dh exchange (lstm_bwd_rs.hip, 2048 rows per launch, larger batches
+// as consecutive launches) and the projection kernel (proj.hip); else 32 units per member, dg exchanged, generic engine.
 static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;
   const int H = (int)d->H, L = d->L;
-  // H = 256: 64 units per member with the waves splitting K (2048 rows per launch, larger batches as consecutive launches);
-  // else 32 units per member, waves split rows.  (Before the contraction-split kernel's weights became register-stationary and
-  // it took over the from-above term, the 32-unit kernel with 128 rows per cluster won from 4096 rows on; now B = 3072:
-  // 864k vs 818k segments/s, 4096: 947k vs 924k, 8192: 999k vs 985k.)
-  const bool ks = H == 256 && !getenv("FHVAE_NO_LAYER_KS");
-  // contraction-split form: a layer below the top computes the from-above term itself (no GEMM, no ws_below round trip)
-  const bool fuse_above = ks && !getenv("FHVAE_NO_FUSE_ABOVE");
-  const bool blk = cluster_dg_blocked(bd);  // (implies ks and fuse_above)
-  const int HU = ks ? 64 : 32;
+  const bool rs = cluster_bwd_rs(d);
+  const int HU = rs ? 64 : 32;
   const int NU = H / HU, NC = kGrid / NU;
   const int64_t B = d->B, T = d->T, G = 4 * H;
-  const int64_t chunk = (int64_t)NC * (ks ? 32 : 128);
+  const int64_t chunk = (int64_t)NC * (rs ? 32 : 128);
   for (int l = L - 1; l >= 0; --l) {
+    if (l < L - 1) {  // ws_below[T*B, H] = dg^{l+1} [T*B, 4H] . W_ih[l+1]  (its transposed bf16 copy [H,4H] is the K-contiguous operand)
+      const u16* dg_up = (const u16*)bd->dgates + (int64_t)(l + 1) * T * B * G;
+      int e;
+      if (rs && proj_eligible(dg_up, G, w.w_ih_t[l + 1], G, bd->ws_below, H, T * B, H, G)) {
+        e = launch_proj(dg_up, G, w.w_ih_t[l + 1], G, bd->ws_below, H, nullptr, T * B, H, G, st);
+      } else {
+        GemmParams g = {};
+        g.seg[0] = Seg{dg_up, G, 1, w.w_ih_t[l + 1], G, 1, (int)G, 0};
+        g.M = (int)(T * B);
+        g.N = H;
+        g.C = bd->ws_below;
+        g.ldc = H;
+        g.splitk = 1;
+        e = launch_gemm(g, FHVAE_BF16, st);
+      }
+      if (e) return e;
+    }
     for (int64_t row0 = 0; row0 < B; row0 += chunk) {
       const int64_t nrows = B - row0 < chunk ? B - row0 : chunk;
       ClBwd p = {};
@@ -2029,11 +1469,7 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.w_hh_t[0] = w.w_hh_t[l];
       p.gates = (const u16*)d->gates + (int64_t)l * T * B * G;
       p.cs = d->cs + (int64_t)l * T * B * H;
-      p.d_hs_top = l == L - 1 ? bd->d_hs_top : (fuse_above ? nullptr : bd->ws_below);
-      if (fuse_above && l < L - 1) {
-        p.dg_above = (const u16*)bd->dgates + (int64_t)(l + 1) * T * B * G;
-        p.w_above_t = w.w_ih_t[l + 1];
-      }
+      p.d_hs_top = l == L - 1 ? bd->d_hs_top : bd->ws_below;
       p.d_hn = bd->d_hn ? bd->d_hn + (int64_t)l * H : nullptr;
       p.hn_ld = L * H;
       p.dg = (u16*)bd->dgates + (int64_t)l * T * B * G;
@@ -2041,66 +1477,30 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.db_ih[0] = bd->db_ih[l];
       p.db_hh[0] = bd->db_hh[l];
       p.sync = (unsigned*)d->lp;
-      p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
       p.xch = w.xch;
-      const bool rs = cluster_bwd_rs(d);  // partial-dh exchange, the from-above term as the launch's prologue (lstm_bwd_rs.hip)
-      if (rs) {
-        p.dg_above = nullptr;
-        p.w_above_t = nullptr;
-        p.tlog_slot = l == L - 1;
-        if (l < L - 1) {  // the from-above term of every step: one projection over the T*B rows of the finished layer above
-          if (row0 == 0) {
-            const int e = launch_proj((const u16*)bd->dgates + (int64_t)(l + 1) * T * B * G, G, w.w_ih_t[l + 1], G, bd->ws_below, H, nullptr,
-                                      T * B, H, G, st);
-            if (e) return e;
-          }
-          p.d_hs_top = bd->ws_below;
-        }
-      }
-      const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * ((T - 1) + (p.dg_above ? T : 0)) * 4.0 * H);
-      const int e = rs ? cluster_bwd_layer_rs(p, st)
-                  : ks ? (RB <= 16 ? launch_bwd_layer_ks<1>(p, blk, st) : launch_bwd_layer_ks<2>(p, blk, st))
-                       : (H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st));
+      p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
+      p.tlog_slot = l == L - 1;
+      const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * (T - 1) * 4.0 * H);
+      const int e = rs ? cluster_bwd_layer_rs(p, st) : (H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st));
       trace_end(st, ts);
-      if (e) return e;
-    }
-    if (l > 0 && !fuse_above) {  // ws_below[T*B, H] = dg^l [T*B, 4H] . W_ih[l]  (its transposed bf16 copy [H,4H] as the KC operand)
-      GemmParams g = {};
-      g.seg[0] = Seg{(const u16*)bd->dgates + (int64_t)l * T * B * G, G, 1, w.w_ih_t[l], G, 1, (int)G, 0};
-      g.M = (int)(T * B);
-      g.N = H;
-      g.C = bd->ws_below;
-      g.ldc = H;
-      g.splitk = 1;
-      const int e = launch_gemm(g, FHVAE_BF16, st);
       if (e) return e;
     }
   }
   return FHVAE_OK;
 }
 
-// the layer-by-layer backward hands the from-above gradient to the lower layer through bd->ws_below (T,B,H) f32 -- unless the
-// lower layer's launch computes that term itself (H = 256, contraction-split kernels)
-// H = 256, rows form: the per-layer backward exchanges partial dh (lstm_bwd_rs.hip)
-static bool cluster_bwd_rs(const fhvae_lstm_desc* d) {
-  return cluster_eligible(d) && cluster_form(d) == 1 && d->H == 256 && !getenv("FHVAE_NO_LAYERWISE") && !getenv("FHVAE_NO_LAYER_KS") &&
-         !getenv("FHVAE_NO_RS");
-}
-
-bool cluster_needs_ws_below(const fhvae_lstm_desc* d) {
-  if (!cluster_eligible(d) || cluster_form(d) != 1 || d->L < 2 || getenv("FHVAE_NO_LAYERWISE")) return false;
-  if (cluster_bwd_rs(d)) return true;  // the lower layer's launch leaves its from-above term there before its recurrence
-  const bool ks = d->H == 256 && !getenv("FHVAE_NO_LAYER_KS");
-  return !(ks && !getenv("FHVAE_NO_FUSE_ABOVE"));
-}
+// the layer-by-layer backward (rows form, two layers or more) hands the from-above gradient to the lower layer through
+// bd->ws_below (T,B,H) f32
+bool cluster_needs_ws_below(const fhvae_lstm_desc* d) { return cluster_eligible(d) && cluster_form(d) == 1 && d->L >= 2; }
 
 int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;
   const int H = (int)d->H, L = d->L;
-  if (cluster_form(d) == 1 && !getenv("FHVAE_NO_LAYERWISE")) {
+  if (cluster_form(d) == 1) {
     if (cluster_needs_ws_below(d) && !bd->ws_below) return FHVAE_ERR_NULL;  // (fhvae_lstm_ws_below_elems says when)
     return cluster_bwd_layers(bd, w, st);
   }
+
   const int NU = H / 16, NC = kGrid / NU;
   const int64_t chunk = (int64_t)NC * 128;
   for (int64_t row0 = 0; row0 < d->B; row0 += chunk) {

@@ -10,8 +10,6 @@ struct WgProblem {
   float* C;      // [M, ldc] f32, accumulated with atomics
   int64_t lda, ldb, ldc;
   int M, N, K;
-  int a_blk_rows;  // 0: A row-major [K, lda].  R > 0: A in the blocked layout of the persistent backward (lstm_cluster.hip, BLK):
-                   // element (k = t*R + b, m) at ((t * (lda/32) + m/32) * R + b) * 32 + m%32; R % 64 == 0, lda % 32 == 0
   // filled by launch_wgrad
   int m_tiles, n_tiles, splitk, ksteps_per;
 };

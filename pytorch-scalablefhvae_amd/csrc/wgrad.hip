@@ -54,18 +54,6 @@ __device__ __forceinline__ void wg_dma_offsets(unsigned (&voff)[WgImg<W>::NI], u
   }
 }
 
-// the same for an A operand in the blocked layout (WgProblem::a_blk_rows = R): 32-column blocks of R rows x 64 B per time slot
-__device__ __forceinline__ void wg_dma_offsets_blk(unsigned (&voff)[WgImg<kWgBM>::NI], unsigned R, int wave, int lane) {
-  using I = WgImg<kWgBM>;
-#pragma unroll
-  for (int q = 0; q < I::NI; ++q) {
-    const int row = (wave * I::NI + q) * I::RPI + lane / I::CPR;
-    const int pc = lane % I::CPR;
-    const int c = ((((pc >> 1) ^ (row & 7)) << 1) | (pc & 1));
-    voff[q] = ((unsigned)(c >> 2) * R + (unsigned)row) * 64u + (unsigned)(c & 3) * 16u;
-  }
-}
-
 template <int W>
 __device__ __forceinline__ void wg_issue(char* stage, __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[WgImg<W>::NI], unsigned kbase,
                                          int wave) {
@@ -92,13 +80,13 @@ __device__ __forceinline__ bf16x8 wg_frag(const char* img, int off, int j) {
   return u.v;
 }
 
-// VAR (FHVAE_WGRAD_VAR; 1 ships): 0 = all DMA pieces of the next stage at the top of a step, counted wait; 1 = the pieces issued
-// in two halves behind each 32-k block's fragment reads (their issue cost then overlaps the LDS latency), plain vmcnt(0) at the
-// top of the next step (they have had a whole step to land); 2 = ablation, no DMA in the loop; 3 = ablation, DMA only (no
-// fragment reads, no MFMAs).  Measured at 4096^3 (64 steps per workgroup + 67 MB of epilogue): 0: 173 us, 1: 159-164 us,
-// 2: 141 us, 3: 98 us -- the fragment-read + MFMA phases between the two barriers of a step bound the loop (~970 TFLOP/s with
-// no DMA at all); a software pipeline over the (32-k block, m-tile) groups pinned with sched_group_barrier was no faster (173 us).
-template <int BN, int VAR>
+// The DMA pieces of the next stage are issued in two halves behind each 32-k block's fragment reads (their issue cost then
+// overlaps the LDS latency), plain vmcnt(0) at the top of the next step (they have had a whole step to land).  Measured at
+// 4096^3 (64 steps per workgroup + 67 MB of epilogue): 159-164 us; all pieces at the top of a step behind a counted wait: 173 us;
+// no DMA in the loop at all: 141 us; DMA only: 98 us -- the fragment-read + MFMA phases between the two barriers of a step bound
+// the loop (~970 TFLOP/s with no DMA); a software pipeline over the (32-k block, m-tile) groups pinned with sched_group_barrier
+// was no faster (173 us).
+template <int BN>
 __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
   using IA = WgImg<kWgBM>;
   using IB = WgImg<BN>;
@@ -139,24 +127,14 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
   // buffer descriptors from the tile's first column: offsets past the last valid k-row read as zero (K tail); columns past
   // M / N inside a row read the neighbouring bytes (in bounds) and only feed output columns that are never stored
   const unsigned lda_b = (unsigned)p.lda * 2u, ldb_b = (unsigned)p.ldb * 2u;
-  const unsigned blkR = (unsigned)p.a_blk_rows;  // > 0: blocked A (the tile's column offset then goes into the step offset)
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u16*>(p.A + (blkR ? 0 : m0)), 0, (int)(((int64_t)p.K * p.lda - (blkR ? 0 : m0)) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsa =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.A + m0), 0, (int)(((int64_t)p.K * p.lda - m0) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsb =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.B + n0), 0, (int)(((int64_t)p.K * p.ldb - n0) * 2), 0x00020000);
   unsigned va[IA::NI], vb[IB::NI];
-  if (blkR)
-    wg_dma_offsets_blk(va, blkR, wave, lane);
-  else
-    wg_dma_offsets<kWgBM>(va, lda_b, wave, lane);
+  wg_dma_offsets<kWgBM>(va, lda_b, wave, lane);
   wg_dma_offsets<BN>(vb, ldb_b, wave, lane);
-  // byte offset of k-step ks of the A operand (uniform): row-major ks * 64 rows; blocked: slot t = k0 / R, rows b0 = k0 % R of
-  // the tile's first 32-column block
-  auto a_step = [&](int ks) -> unsigned {
-    if (!blkR) return (unsigned)(ks * kWgBK) * lda_b;
-    const unsigned k0 = (unsigned)(ks * kWgBK), t = k0 / blkR, b0 = k0 - t * blkR;
-    return ((t * (unsigned)(p.lda >> 5) + (unsigned)(m0 >> 5)) * blkR + b0) * 64u;
-  };
+  auto a_step = [&](int ks) -> unsigned { return (unsigned)(ks * kWgBK) * lda_b; };  // byte offset of k-step ks (uniform)
 
   // fragment read offsets: k-row 4g + (i >> 2) of the 32-k block, 32-byte segment (col0 / 16) ^ (k & 7), 8 bytes per lane
   const int kr = 4 * gq + (i >> 2), x = kr & 7;
@@ -181,7 +159,6 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
   };
   auto compute = [&](const char* As, char* nxt, int ks_next) {
     const char* Bs = As + IA::BYTES;
-    if constexpr (VAR == 3) return;
 #pragma unroll
     for (int j = 0; j < kWgBK / 32; ++j) {
       bf16x8 a[TM], b[TN];
@@ -189,7 +166,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
       for (int tn = 0; tn < TN; ++tn) b[tn] = wg_frag<IB::RB>(Bs, offb[tn], j);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) a[tm] = wg_frag<IA::RB>(As, offa[tm], j);
-      if constexpr (VAR == 1) {  // this half of the next stage's DMA pieces: issued while the fragment reads are in flight
+      {  // this half of the next stage's DMA pieces: issued while the fragment reads are in flight
         const bool in = ks_next < ks1;
         if (j == 0)
           wg_issue<kWgBM>(nxt, rsa, va, in ? a_step(ks_next) : kOob, wave);
@@ -204,18 +181,11 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
       __builtin_amdgcn_s_setprio(0);
     }
   };
-  // One K-step: the next stage's DMA is issued first and stays in flight under this stage's MFMAs (its buffer was released by
-  // the barrier that ended the previous step); the counted wait leaves exactly those NLOAD pieces outstanding.  The loop body
-  // is branch-free (a wait whose count depends on a branch makes hipcc merge the paths' counts into vmcnt(0)) and handles
-  // two steps (one per LDS object): an odd slice gets one padding step whose operands are the zeros of out-of-range loads,
-  // and the look-ahead DMA of the last step is such a zero fill too.
+  // One K-step: the next stage's DMA stays in flight under this stage's MFMAs (its buffer was released by the barrier that ended
+  // the previous step).  The loop body is branch-free and handles two steps (one per LDS object): an odd slice gets one padding
+  // step whose operands are the zeros of out-of-range loads, and the look-ahead DMA of the last step is such a zero fill too.
   auto step = [&](const char* cur, char* nxt, int ks_next) {
-    if constexpr (VAR == 0 || VAR == 3) {
-      issue(nxt, ks_next);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's pieces of the current stage have landed
     compute(cur, nxt, ks_next);
     __builtin_amdgcn_s_barrier();  // every wave is done reading it: the next step may refill it
@@ -247,12 +217,8 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
     }
 }
 
-template __global__ void wgrad_kernel<256, 0>(WgGroup);
-template __global__ void wgrad_kernel<256, 1>(WgGroup);
-template __global__ void wgrad_kernel<256, 2>(WgGroup);
-template __global__ void wgrad_kernel<256, 3>(WgGroup);
-template __global__ void wgrad_kernel<128, 0>(WgGroup);
-template __global__ void wgrad_kernel<128, 1>(WgGroup);
+template __global__ void wgrad_kernel<256>(WgGroup);
+template __global__ void wgrad_kernel<128>(WgGroup);
 
 bool wgrad_eligible(const WgProblem& p) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.B || !p.C) return false;
@@ -260,7 +226,6 @@ bool wgrad_eligible(const WgProblem& p) {
   if ((p.lda % 8) || (p.ldb % 8) || p.lda < p.M || p.ldb < p.N) return false;
   // 32-bit buffer offsets / num_records
   if ((int64_t)p.K * p.lda * 2 >= (1LL << 30) || (int64_t)p.K * p.ldb * 2 >= (1LL << 30)) return false;
-  if (p.a_blk_rows < 0 || (p.a_blk_rows > 0 && ((p.a_blk_rows % 64) || (p.lda % 32) || (p.K % p.a_blk_rows)))) return false;
   return true;
 }
 
@@ -302,16 +267,8 @@ static int launch_class(const WgProblem* ps, const int* which, int n, hipStream_
       g.p[k] = p;
       g.base[k + 1] = g.base[k] + p.m_tiles * p.n_tiles * p.splitk;
     }
-    static const int var = getenv("FHVAE_WGRAD_VAR") ? atoi(getenv("FHVAE_WGRAD_VAR")) : 1;
     const dim3 grid((unsigned)g.base[cnt]), block(kWgThreads);
-    if (var == 0)
-      hipLaunchKernelGGL((wgrad_kernel<BN, 0>), grid, block, 0, st, g);
-    else if (BN == 256 && var == 2)
-      hipLaunchKernelGGL((wgrad_kernel<256, 2>), grid, block, 0, st, g);
-    else if (BN == 256 && var == 3)
-      hipLaunchKernelGGL((wgrad_kernel<256, 3>), grid, block, 0, st, g);
-    else
-      hipLaunchKernelGGL((wgrad_kernel<BN, 1>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((wgrad_kernel<BN>), grid, block, 0, st, g);
     const int e = fh_launch_status();
     if (e) return e;
   }

@@ -564,7 +564,7 @@ def lstm_kernel_names(form: int, H: int) -> dict:
     names = {0: kn % "fwd", 1: kn % "bwd"}
     if form == 1 and not os.environ.get("FHVAE_NO_LAYERWISE"):
         # rows form: the backward runs one persistent launch per layer (contraction-split variant at H = 256)
-        names[1] = "lstm_bwd_layer_ks_kernel" if H == 256 else "lstm_bwd_layer_kernel"
+        names[1] = "lstm_bwd_layer_rs_kernel" if H == 256 else "lstm_bwd_layer_kernel"
     return names
 
 

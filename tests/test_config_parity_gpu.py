@@ -92,17 +92,15 @@ def test_bench_shape_bf16_lstm_fwd_bwd_vs_torch_lstm(hb, I, Ic):
 @pytest.mark.parametrize("B,T,I,Ic,H,L", [(256, 6, 80, 32, 512, 2), (256, 5, 80, 0, 512, 2), (384, 4, 0, 64, 512, 2), (1024, 3, 80, 32, 512, 2),
                                            (256, 4, 80, 32, 256, 1), (128, 4, 0, 64, 384, 2)])
 def test_big_cells_h512_bf16_vs_torch_lstm_and_generic_cells(hb, monkeypatch, B, T, I, Ic, H, L):
-    """The large-tile bf16 cells for H = 512 (configs[3] at the bench batch), forced on at a batch the CPU oracle handles, in both
-    forms -- one launch per wavefront step (lstm_cell.hip, the default) and one persistent launch per direction (lstm_stream.hip,
-    opt-in: FHVAE_STREAM=1) -- against
+    """The large-tile bf16 cells for H = 512 (configs[3] at the bench batch: lstm_cell.hip, one launch per wavefront step), forced on
+    at a batch the CPU oracle handles, against
     torch.nn.LSTM with the bf16 tolerances of the tests above, and against the generic step cells on the same inputs (same bf16
     operands, f32 accumulation; only the summation order differs): relative Frobenius error < 4e-3.  The H = 256 / 384 cases
     (one and two layers; the persistent cluster kernels switched off) cover the other unit-tile counts."""
-    monkeypatch.setenv("FHVAE_NO_CLUSTER", "1")  # (H = 256 would take lstm_cluster.hip; also switches the streaming form off)
+    monkeypatch.setenv("FHVAE_NO_CLUSTER", "1")  # (H = 256 would take lstm_cluster.hip)
     res = {}
-    for mode, big, stream in (("stream", "1", "1"), ("cells", "1", "0"), ("generic", "0", "0")):
+    for mode, big in (("cells", "1"), ("generic", "0")):
         monkeypatch.setenv("FHVAE_BIG_CELLS", big)
-        monkeypatch.setenv("FHVAE_STREAM", stream)
         lstm, names, params, (out, hn_cat, xc), (hs_top, hnd, xcd) = _lstm_case(hb, B, T, I, Ic, H, L, "bf16", seed=7 * B + I + Ic)
         close(hs_top.transpose(0, 1), out, rtol=3e-2, what="hs_top " + mode)
         close(hnd, hn_cat, rtol=3e-2, what="hn " + mode)
@@ -114,7 +112,7 @@ def test_big_cells_h512_bf16_vs_torch_lstm_and_generic_cells(hb, monkeypatch, B,
             close(xcd.grad, xc.grad, rtol=6e-2, what="dxc " + mode)
             got["dxc"] = xcd.grad.detach().cpu().double()
         res[mode] = got
-    for mode in ("stream", "cells"):
+    for mode in ("cells",):
         for k in res[mode]:
             a, b = res[mode][k], res["generic"][k]
             rel = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()

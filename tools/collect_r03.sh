@@ -46,5 +46,17 @@ for w in $WHAT; do
       python3 $R/tools/pmc_quick.py /tmp/pmc_fetch /tmp/pmc_write > $O/pmc_fetch_write_top.txt 2>&1 || true
       echo pmc done
       ;;
+    stall)  # stall attribution of the recurrent kernels and the GEMMs around them: separate SQ / TCC passes (8 SQ slots, 4 TCC slots per pass)
+      ARGS="--no-graph --no-roofline --no-cpu-baseline --no-alt --steps 6 --warmup 2"
+      K="lstm_bwd_layer_rs_kernel,lstm_fwd_cluster_kernel,lstm_fwd_rs_kernel,proj_kernel,wgrad_kernel"
+      rm -rf /tmp/pmc_s1 /tmp/pmc_s2 /tmp/pmc_s3 /tmp/pmc_s4
+      rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_s1 -- python3 $R/bench.py $ARGS > $O/pmc_s1.log 2>&1
+      rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_s2 -- python3 $R/bench.py $ARGS > $O/pmc_s2.log 2>&1
+      rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM --kernel-trace --output-format csv -d /tmp/pmc_s3 -- python3 $R/bench.py $ARGS > $O/pmc_s3.log 2>&1
+      rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum --kernel-trace --output-format csv -d /tmp/pmc_s4 -- python3 $R/bench.py $ARGS > $O/pmc_s4.log 2>&1
+      python3 $R/tools/pmc_table.py $K /tmp/pmc_s1 /tmp/pmc_s2 /tmp/pmc_s3 /tmp/pmc_s4 /tmp/pmc_fetch /tmp/pmc_write /tmp/pmc_mfma > $O/pmc_stall_table.txt 2>&1 || true
+      tail -3 $O/pmc_s1.log $O/pmc_s2.log $O/pmc_s3.log $O/pmc_s4.log > $O/pmc_stall_logs_tail.txt 2>&1 || true
+      echo stall done
+      ;;
   esac
 done
