@@ -47,7 +47,7 @@ struct RsCfg {
   static constexpr int SMEM = RT * 16 * 512;  // dg_t image: [RT*16 rows][32 chunks]
 };
 
-template <int RT>
+template <int RT, bool UM>
 __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
   constexpr int H = kH, G = kG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,7 +106,13 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
     const int t = T - 1 - sn;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      cl_load_gates(p.gates + ((int64_t)t * B + rowc[rt]) * G, uq, gkn[rt]);
+      if constexpr (UM) {  // unit-major (lstm_fwd_wr.hip): [unit][i,f,g,o] -> this lane's 4 units are 32 contiguous bytes
+        const u16* gp = p.gates + ((int64_t)t * B + rowc[rt]) * G + uq * 4;
+        const uint4 a = *(const uint4*)gp, b = *(const uint4*)(gp + 8);
+        gkn[rt][0] = uint2{a.x, a.y}, gkn[rt][1] = uint2{a.z, a.w}, gkn[rt][2] = uint2{b.x, b.y}, gkn[rt][3] = uint2{b.z, b.w};
+      } else {
+        cl_load_gates(p.gates + ((int64_t)t * B + rowc[rt]) * G, uq, gkn[rt]);
+      }
       if (sn == 0) ccurn[rt] = *(const f32x4*)(p.cs + ((int64_t)t * B + rowc[rt]) * H + uq);
       cprevn[rt] = t > 0 ? *(const f32x4*)(p.cs + ((int64_t)(t - 1) * B + rowc[rt]) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -167,7 +173,16 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
     uint2 dpk[RT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const f32x4 ig = unpack4(gk[rt][0]), fg = unpack4(gk[rt][1]), gg = unpack4(gk[rt][2]), og = unpack4(gk[rt][3]);
+      f32x4 ig, fg, gg, og;
+      if constexpr (UM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ig[i] = bf2f((u16)(gk[rt][i].x & 0xffff)), fg[i] = bf2f((u16)(gk[rt][i].x >> 16));
+          gg[i] = bf2f((u16)(gk[rt][i].y & 0xffff)), og[i] = bf2f((u16)(gk[rt][i].y >> 16));
+        }
+      } else {
+        ig = unpack4(gk[rt][0]), fg = unpack4(gk[rt][1]), gg = unpack4(gk[rt][2]), og = unpack4(gk[rt][3]);
+      }
       f32x4 dp[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -271,7 +286,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
 
 template <int RT>
 int launch_rs(const ClBwd& p, hipStream_t st) {
-  hipLaunchKernelGGL((lstm_bwd_layer_rs_kernel<RT>), dim3(kGrid), dim3(kThreads), RsCfg<RT>::SMEM, st, p);
+  if (p.gates_um)
+    hipLaunchKernelGGL((lstm_bwd_layer_rs_kernel<RT, true>), dim3(kGrid), dim3(kThreads), RsCfg<RT>::SMEM, st, p);
+  else
+    hipLaunchKernelGGL((lstm_bwd_layer_rs_kernel<RT, false>), dim3(kGrid), dim3(kThreads), RsCfg<RT>::SMEM, st, p);
   return fh_launch_status();
 }
 

@@ -39,6 +39,8 @@ int cluster_form(const fhvae_lstm_desc* d);
 // the forward kernels can multiply x_t by W_ih[0][:, :I] themselves (I a multiple of 8, at most 128, rows 16-byte aligned)
 bool cluster_can_fold(const fhvae_lstm_desc* d);
 bool cluster_xc_in_kernel(const fhvae_lstm_desc* d);
+// the forward runs with register-stationary weights and saves the gates unit-major (lstm_fwd_wr.hip)
+bool cluster_fwd_wr_ok(const fhvae_lstm_desc* d);
 // the recurrence of fhvae_lstm_seq_fwd after the layer-0 input projection (d->pre filled): all T steps, all layers
 int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st);
 // the backward needs fhvae_lstm_bwd_desc.ws_below

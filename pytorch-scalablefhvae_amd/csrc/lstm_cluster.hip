@@ -93,35 +93,6 @@ __device__ __forceinline__ void wait_panels(int younger) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-struct ClFwd {
-  int B, T, NU, Mc;    // B: row count of the (T,B,.) buffers; NU workgroups per cluster; Mc rows per cluster
-  int row0, nrows;     // rows handled by this launch
-  const u16* w_ih[2];  // [4H,H] bf16 (l = 1)
-  const u16* w_hh[2];
-  const float* b_ih[2];
-  const float* b_hh[2];
-  const float* pre;  // layer-0 additive term incl. biases: (T,B,4H), or (B,4H) with pre_tstride = 0, or NULL (= biases)
-  int64_t pre_tstride;
-  // folded input projection (x != NULL): the kernels multiply x_t (T,B,I) bf16 by this member's rows of W_ih[0][:, :I]
-  // themselves (fragments stationary in registers); `pre` then only holds the time-constant part
-  const u16* x;
-  const u16* w_ih0;  // [4H,K0] bf16
-  int I, K0;
-  u16* hs;     // (L,T,B,H)
-  float* cs;   // (L,T,B,H)
-  u16* gates;  // (L,T,B,4H)
-  float* hs_top_f32;  // optional (T,B,H)
-  float* hn;          // optional (B, L*H)
-  u16* xch;  // exchange buffer (blocked copy of h; contraction-split form), see xch_off
-  unsigned* sync;
-  unsigned long long* tlog;  // optional phase clock log of cluster 0 / member 0 (tools/prof_cluster.py)
-  int il;                    // rows form, L = 2: layer 0's gate math between the MFMAs of the h^1 panels
-  // the time-constant input xc (B,Ic) bf16 is projected by the kernel itself, once, into layer 0's additive term
-  // (W_ih[0][:, I:I+Ic] from w_ih0); `pre` is then NULL and no GEMM runs before the launch
-  const u16* xcv;
-  int Ic;
-};
-
 template <int H, int L, int RB>
 struct ClFwdCfg {
   static constexpr int HC = H / 8;                        // 16-byte chunks per h row
@@ -1310,10 +1281,23 @@ int cluster_form(const fhvae_lstm_desc* d) {
   return RB <= 32 ? 2 : 1;
 }
 
+static bool cluster_bwd_rs(const fhvae_lstm_desc* d);
+
+// H = 256, two layers, rows form, the inputs foldable: the forward with register-stationary weights (lstm_fwd_wr.hip).  It saves the
+// activated gates unit-major, which only the partial-dh backward reads (ClBwd::gates_um): both follow from this one predicate.
+bool cluster_fwd_wr_ok(const fhvae_lstm_desc* d) {
+  if (!cluster_bwd_rs(d) || d->L != 2 || getenv("FHVAE_NO_FWD_WR")) return false;
+  if (d->I > 0 && !cluster_can_fold(d)) return false;
+  if (d->Ic > 0 && !cluster_xc_in_kernel(d)) return false;
+  if ((int64_t)2 * d->T * d->B * d->H * 2 >= (1LL << 31) || (int64_t)d->T * d->B * d->I * 2 >= (1LL << 31)) return false;  // 32-bit buffer offsets
+  return d->I > 0 || d->Ic > 0;
+}
+
 int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st) {
   const int H = (int)d->H, L = d->L;
-  const int NU = H / 16, NC = kGrid / NU;
-  const int64_t chunk = (int64_t)NC * 128;
+  const bool wr = cluster_fwd_wr_ok(d);
+  const int NU = wr ? 8 : H / 16, NC = kGrid / NU;
+  const int64_t chunk = (int64_t)NC * (wr ? 64 : 128);
   for (int64_t row0 = 0; row0 < d->B; row0 += chunk) {
     const int64_t nrows = d->B - row0 < chunk ? d->B - row0 : chunk;
     ClFwd p = {};
@@ -1363,7 +1347,10 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     for (int l = 0; l < L; ++l) fl += 2.0 * nrows * 4 * H * ((l > 0 ? d->T * H : 0) + (d->T - 1) * (double)H);
     const int ts = trace_begin(st, kTraceFwdCell, fl);
     int e;
-    if (H == 256)
+    if (wr) {
+      p.gates_um = 1;
+      e = cluster_fwd_wr(p, st);
+    } else if (H == 256)
       e = L == 1 ? launch_fwd<256, 1>(p, RB, st) : launch_fwd<256, 2>(p, RB, st);
     else
       e = L == 1 ? launch_fwd<128, 1>(p, RB, st) : launch_fwd<128, 2>(p, RB, st);
@@ -1480,6 +1467,7 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.xch = w.xch;
       p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
       p.tlog_slot = l == L - 1;
+      p.gates_um = cluster_fwd_wr_ok(d) ? 1 : 0;  // the forward on this workspace saved the gates unit-major (same predicate)
       const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * (T - 1) * 4.0 * H);
       const int e = rs ? cluster_bwd_layer_rs(p, st) : (H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st));
       trace_end(st, ts);

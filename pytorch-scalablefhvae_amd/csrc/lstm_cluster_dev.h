@@ -167,6 +167,7 @@ struct ClBwd {
   // itself from the finished layer above (row-major dg, (T,B,4H)) instead of being handed in through d_hs_top
   const u16* dg_above;
   const u16* w_above_t;  // W_ih[l+1]^T, [H,4H] bf16
+  int gates_um;          // the forward saved the gates unit-major (lstm_fwd_wr.hip): [row][unit][i,f,g,o] bf16
   int tlog_slot;         // lstm_bwd_rs.hip: which half of the phase-clock log this launch writes (tools/prof_rs.py)
 };
 
@@ -176,6 +177,39 @@ __device__ __forceinline__ f32x4 unpack4(uint2 v) {
 __device__ __forceinline__ uint2 pack4(const f32x4& v) {
   return uint2{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
 }
+
+struct ClFwd {
+  int B, T, NU, Mc;    // B: row count of the (T,B,.) buffers; NU workgroups per cluster; Mc rows per cluster
+  int row0, nrows;     // rows handled by this launch
+  const u16* w_ih[2];  // [4H,H] bf16 (l = 1)
+  const u16* w_hh[2];
+  const float* b_ih[2];
+  const float* b_hh[2];
+  const float* pre;  // layer-0 additive term incl. biases: (T,B,4H), or (B,4H) with pre_tstride = 0, or NULL (= biases)
+  int64_t pre_tstride;
+  // folded input projection (x != NULL): the kernels multiply x_t (T,B,I) bf16 by this member's rows of W_ih[0][:, :I]
+  // themselves (fragments stationary in registers); `pre` then only holds the time-constant part
+  const u16* x;
+  const u16* w_ih0;  // [4H,K0] bf16
+  int I, K0;
+  u16* hs;     // (L,T,B,H)
+  float* cs;   // (L,T,B,H)
+  u16* gates;  // (L,T,B,4H)
+  float* hs_top_f32;  // optional (T,B,H)
+  float* hn;          // optional (B, L*H)
+  u16* xch;  // exchange buffer (blocked copy of h; contraction-split form), see xch_off
+  unsigned* sync;
+  unsigned long long* tlog;  // optional phase clock log of cluster 0 / member 0 (tools/prof_cluster.py)
+  int il;                    // rows form, L = 2: layer 0's gate math between the MFMAs of the h^1 panels
+  // the time-constant input xc (B,Ic) bf16 is projected by the kernel itself, once, into layer 0's additive term
+  // (W_ih[0][:, I:I+Ic] from w_ih0); `pre` is then NULL and no GEMM runs before the launch
+  const u16* xcv;
+  int Ic;
+  int gates_um;  // lstm_fwd_wr.hip: the saved gates are unit-major ([row][unit][i,f,g,o]); the backward launches get the same flag
+};
+
+// lstm_fwd_wr.hip: forward of a two-layer H = 256 net, weights register-stationary (p.NU = 8, p.Mc <= 64, x / xc folded)
+int cluster_fwd_wr(const ClFwd& p, hipStream_t st);
 
 // lstm_bwd_rs.hip: backward of ONE layer, H = 256, partial-dh exchange (p.NU = 4, p.Mc <= 32); p.xch holds kRsXchElems bf16 elements
 int cluster_bwd_layer_rs(const ClBwd& p, hipStream_t st);

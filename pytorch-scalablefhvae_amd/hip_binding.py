@@ -562,9 +562,12 @@ def lstm_kernel_names(form: int, H: int) -> dict:
     """{0: forward, 1: backward} kernel names of the recurrence schedule `form` (fhvae_lstm_form) as rocprofv3 lists them."""
     kn = {0: "lstm_%s_step_kernel", 1: "lstm_%s_cluster_kernel", 2: "lstm_%s_ksplit_kernel"}[form]
     names = {0: kn % "fwd", 1: kn % "bwd"}
-    if form == 1 and not os.environ.get("FHVAE_NO_LAYERWISE"):
-        # rows form: the backward runs one persistent launch per layer (contraction-split variant at H = 256)
-        names[1] = "lstm_bwd_layer_rs_kernel" if H == 256 else "lstm_bwd_layer_kernel"
+    if form == 1:
+        # rows form: the backward runs one persistent launch per layer (H = 256: partial-dh exchange, lstm_bwd_rs.hip), the
+        # forward of a two-layer H = 256 net with register-stationary weights (lstm_fwd_wr.hip)
+        names[1] = "lstm_bwd_layer_rs_kernel" if H == 256 and not os.environ.get("FHVAE_NO_RS") else "lstm_bwd_layer_kernel"
+        if H == 256 and not os.environ.get("FHVAE_NO_RS") and not os.environ.get("FHVAE_NO_FWD_WR"):
+            names[0] = "lstm_fwd_wr_kernel"
     return names
 
 

@@ -139,10 +139,14 @@ def test_partial_dh_backward_vs_dg_exchange(hb, B, T, Ic):
         assert hb.lstm_sync_status() == 0
     finally:
         os.environ.pop("FHVAE_NO_RS", None)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])  # the forward is the same launch
+    # the forward differs too (register-stationary weights, lstm_fwd_wr.hip, only beside the partial-dh backward): same bf16
+    # products in another order
+    for u, v in ((a[0], b[0]), (a[1], b[1])):
+        d = (u - v).abs()
+        assert d.max().item() < 2e-2 and d.mean().item() < 5e-4
     for ga, gb, n in zip(a[2], b[2], names):
         err = (ga - gb).abs().max().item()
-        assert err <= 2e-3 * gb.abs().max().item() + 1e-6, (n, err, gb.abs().max().item())
+        assert err <= 2e-2 * gb.abs().max().item() + 1e-6, (n, err, gb.abs().max().item())
     if Ic:
         err = (a[3] - b[3]).abs().max().item()
-        assert err <= 2e-3 * b[3].abs().max().item() + 1e-6, ("d_xc", err)
+        assert err <= 2e-2 * b[3].abs().max().item() + 1e-6, ("d_xc", err)

@@ -48,7 +48,7 @@ for w in $WHAT; do
       ;;
     stall)  # stall attribution of the recurrent kernels and the GEMMs around them: separate SQ / TCC passes (8 SQ slots, 4 TCC slots per pass)
       ARGS="--no-graph --no-roofline --no-cpu-baseline --no-alt --steps 6 --warmup 2"
-      K="lstm_bwd_layer_rs_kernel,lstm_fwd_cluster_kernel,lstm_fwd_rs_kernel,proj_kernel,wgrad_kernel"
+      K="lstm_bwd_layer_rs_kernel,lstm_fwd_cluster_kernel,lstm_fwd_wr_kernel,proj_kernel,wgrad_kernel"
       rm -rf /tmp/pmc_s1 /tmp/pmc_s2 /tmp/pmc_s3 /tmp/pmc_s4
       rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_s1 -- python3 $R/bench.py $ARGS > $O/pmc_s1.log 2>&1
       rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_s2 -- python3 $R/bench.py $ARGS > $O/pmc_s2.log 2>&1

@@ -10,7 +10,8 @@ acc = {}
 for d in sys.argv[2:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            n = re.sub(r"\(.*", "", r["Kernel_Name"])
+            n = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+            n = re.sub(r"\(.*", "", n)
             n = re.sub(r"^void ", "", n)
             if not any(p in n for p in pats):
                 continue

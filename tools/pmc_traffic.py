@@ -39,7 +39,7 @@ def main():
     res = json.load(open(path)) if os.path.exists(path) else {}
     tname = {"bf16": "unsigned short", "f32": "float"}[dtype]
     for short in ("lstm_fwd_step_kernel", "lstm_bwd_step_kernel", "lstm_fwd_cluster_kernel", "lstm_bwd_cluster_kernel",
-                  "lstm_fwd_ksplit_kernel", "lstm_bwd_ksplit_kernel", "lstm_bwd_layer_kernel", "lstm_bwd_layer_ks_kernel", "lstm_bwd_layer_rs_kernel", "wgrad_kernel",
+                  "lstm_fwd_ksplit_kernel", "lstm_bwd_ksplit_kernel", "lstm_bwd_layer_kernel", "lstm_bwd_layer_ks_kernel", "lstm_bwd_layer_rs_kernel", "lstm_fwd_wr_kernel", "proj_kernel", "wgrad_kernel",
                   "disc_mfma_kernel"):
         typed = "step_kernel" in short  # the persistent kernels are bf16 only (no element type in their names)
         f = [(k, v) for k, v in fe.items() if short in k and (tname in k or not typed)]
