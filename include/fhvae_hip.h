@@ -156,6 +156,12 @@ int64_t fhvae_lstm_lp_bytes(const fhvae_lstm_desc* d);
    input projection is theirs; they then REQUIRE 16-byte aligned buffers: the forward returns FHVAE_ERR_ALIGN instead of
    falling back to a schedule that would need the full buffer).  `pre` must still be non-NULL. */
 int64_t fhvae_lstm_pre_elems(const fhvae_lstm_desc* d);
+/* Identifies the layout of what fhvae_lstm_seq_fwd saves for the backward (gates, schedule workspaces): it follows from the
+ * schedule the library picks for this descriptor AND the FHVAE_* environment switches at call time.  A caller that may change
+ * either between a forward and its backward keeps the forward's value and checks it before fhvae_lstm_seq_bwd (< 0: bad
+ * descriptor). */
+int fhvae_lstm_layout_id(const fhvae_lstm_desc* d);
+
 /* Floats fhvae_lstm_bwd_desc.ws_below must hold (0: may be NULL). */
 int64_t fhvae_lstm_ws_below_elems(const fhvae_lstm_desc* d);
 /* Which schedule fhvae_lstm_seq_fwd/_bwd take for this descriptor on the current device: 0 = one launch per wavefront

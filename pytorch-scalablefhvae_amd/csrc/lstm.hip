@@ -634,6 +634,16 @@ extern "C" int fhvae_lstm_form(const fhvae_lstm_desc* d) {
   return cluster_form(d);
 }
 
+// What decides the layouts of the tensors a forward saves for its backward (gates, the schedule-specific workspaces): the schedule
+// (per-step cells, large-tile cells, persistent rows / contraction-split form) and its variants (register-stationary forward:
+// unit-major gates).  The schedule is re-derived per call from the descriptor and the environment: a caller keeps the forward's
+// value and compares it before the backward (hip_binding does; a mismatch would otherwise be silently wrong gradients).
+extern "C" int fhvae_lstm_layout_id(const fhvae_lstm_desc* d) {
+  if (!d || check_desc(d) != FHVAE_OK) return -1;
+  if (d->dtype == FHVAE_BF16 && cluster_eligible(d)) return 16 + cluster_form(d) * 2 + (cluster_fwd_wr_ok(d) ? 1 : 0);
+  return big_cells(d->B, d->H, d->dtype) && big_shape_ok(d) ? 1 : 0;
+}
+
 extern "C" int64_t fhvae_lstm_pre_elems(const fhvae_lstm_desc* d) {
   if (!d || d->L < 1 || d->L > FHVAE_MAX_LAYERS || d->B <= 0 || d->T <= 0 || d->H <= 0) return 0;
   const int64_t full = (d->I > 0 ? d->T : 1) * d->B * 4 * d->H;

@@ -12,6 +12,7 @@ struct WgProblem {
   int M, N, K;
   // filled by launch_wgrad
   int m_tiles, n_tiles, splitk, ksteps_per;
+  int shared_c;  // another problem of the same launch accumulates into the same C: atomics even without a K split
 };
 
 constexpr int kMaxWgProblems = 16;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
         const int m = m0 + wm * 128 + tm * 16 + 4 * gq + r;
         if (m < p.M && n < p.N) {
           float* c = p.C + (int64_t)m * p.ldc + n;
-          if (p.splitk == 1)
+          if (p.splitk == 1 && !p.shared_c)
             *c += acc[tm][tn][r];  // the only workgroup on this tile: plain read-modify-write (the atomic path adds ~1.3 TB/s)
           else
             atomicAdd(c, acc[tm][tn][r]);
@@ -267,6 +267,11 @@ static int launch_class(const WgProblem* ps, const int* which, int n, hipStream_
       g.p[k] = p;
       g.base[k + 1] = g.base[k] + p.m_tiles * p.n_tiles * p.splitk;
     }
+    // two problems of one launch that accumulate into the same matrix (a net queued twice: gradient accumulation over two
+    // backward passes before one optimizer step) must not take the plain read-modify-write path
+    for (int a = 0; a < cnt; ++a)
+      for (int b = 0; b < cnt; ++b)
+        if (a != b && g.p[a].C == g.p[b].C) g.p[a].shared_c = 1;
     const dim3 grid((unsigned)g.base[cnt]), block(kWgThreads);
     hipLaunchKernelGGL((wgrad_kernel<BN>), grid, block, 0, st, g);
     const int e = fh_launch_status();

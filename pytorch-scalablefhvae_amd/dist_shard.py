@@ -1,16 +1,18 @@
 """Multi-GPU: data parallel over the minibatch + row-sharded mu2 table.
 
 One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm).  Net weights are
-replicated; rank r owns table rows [row0, row1) and their Adam moments.  Per training step:
+replicated; rank r owns table rows [row0, row1) and their Adam moments.  FIVE collectives per training step,
+all latency-bound (O(B*D) bytes; no table row ever moves):
 
-  forward   all-gather idx, z2_mu (B_local*D*4 bytes per rank)            -- C2 of SURVEY 8e
-            rows   : owners gather their rows for ALL global queries, reduce-scatter -> mu2 of the local batch
-            K5     : each rank scans ITS rows for all global queries -> (max, sumexp, target) partials,
-                     all-reduce(MAX) max, rescale, all-reduce(SUM) (sumexp, target) -> CE (same on all ranks)
-  backward  dtable : local rows, complete, no exchange;   dq : reduce-scatter to the query's owner
-            dmu2   : all-gather, owners scatter-add
-            nets   : ONE all-reduce over the flat gradient arena; 1/W is folded into Adam's grad_scale
-All exchanged messages are O(B*D): latency-bound on xGMI, no table rows ever move.
+  forward   (1) all-gather  [z2_mu | idx]            one packed (B_local, D+1) f32 buffer (idx as int32 bits)   -- C2 of SURVEY 8e
+            (2) reduce-scatter of the owners' rows   -> mu2 of the local batch (owners gather their rows for ALL global queries)
+            (3) all-gather of (max, sumexp, target)  each rank scans ITS rows for all global queries (K5); the W partials are
+                                                     combined locally (log-sum-exp merge): replaces all-reduce(MAX) + all-reduce(SUM)
+  backward  (4) all-reduce  [dq | dmu2]              one (B_global, 2D) buffer: every rank's partial dq for all queries (summed,
+                                                     the owner keeps its slice) and the local queries' dmu2 in their rows (the row
+                                                     owners scatter-add them); dtable of the CE term is complete locally
+            (5) all-reduce of the net gradients      flat arena; 1/W is folded into Adam's grad_scale; the decoder + z1 buckets go out
+                                                     under the z2 encoder's weight-gradient launch (DistributedFHVAE._on_lstm_rec_done)
 
 The local arithmetic goes through a `backend` object.  The product backend is `HipBackend` (the HIP kernels);
 tests pass an oracle backend to exercise the collective logic on CPU with gloo.  There is no automatic
@@ -120,82 +122,83 @@ class ShardCtx:
         return out
 
 
-class _ShardGather(torch.autograd.Function):
-    """mu2 rows of the local batch out of the row-sharded table (replaces torch.gather, simple_fhvae.py:53)."""
+class _ShardTable(torch.autograd.Function):
+    """(mu2 rows of the local batch, CE of the local queries against the WHOLE table) out of the row-sharded table: replaces
+    torch.gather (simple_fhvae.py:53) and the (B,S,D) log-sum-exp cross-entropy (simple_fhvae.py:119-122; the mean over the
+    GLOBAL batch, identical on every rank).  Three collectives forward, one backward (module docstring)."""
 
     @staticmethod
-    def forward(ctx, shard, idx_all, sh: ShardCtx):
-        rows_all = sh.backend.gather_rows(shard, idx_all, sh.row0)  # zeros for rows owned elsewhere
+    def forward(ctx, q_local, shard, idx_local, sh: ShardCtx):
+        be = sh.backend
+        D = q_local.shape[1]
+        # (1) one buffer: the queries and, in the last column, the row indices as int32 bit patterns
+        pk = torch.cat([q_local.detach().float(), idx_local.to(torch.int32).view(torch.float32).reshape(-1, 1)], dim=1)
+        pk_all = sh.all_gather(pk)
+        q_all = pk_all[:, :D].contiguous()
+        idx_all = pk_all[:, D].contiguous().view(torch.int32).to(torch.int64)
+        # (2) rows: zeros for rows owned elsewhere, so the sum over ranks is the row
+        mu2 = sh.reduce_scatter(be.gather_rows(shard, idx_all, sh.row0))
+        # (3) K5 partials of this shard for ALL queries, merged locally
+        rmax, rsum, tgt = be.disc_partials(q_all, shard, idx_all, sh.row0)
+        parts = sh.all_gather(torch.stack([rmax, rsum, tgt], dim=1)).view(sh.world, -1, 3)
+        m = parts[:, :, 0].max(dim=0).values
+        s = (parts[:, :, 1] * torch.exp(parts[:, :, 0] - m)).sum(dim=0)  # (an empty shard's (-inf, 0) contributes exp(-inf) * 0 = 0)
+        t = parts[:, :, 2].sum(dim=0)
+        ce = be.ce_mean(m.contiguous(), s.contiguous(), t.contiguous())
         ctx.sh, ctx.shape = sh, tuple(shard.shape)
         ctx.sink = getattr(shard, "_fh_grad", None)
-        ctx.save_for_backward(idx_all)
-        return sh.reduce_scatter(rows_all)
+        ctx.save_for_backward(q_all, shard, idx_all, m.contiguous(), s.contiguous())
+        ctx.mark_non_differentiable(idx_all)
+        return mu2, ce, idx_all
 
     @staticmethod
-    def backward(ctx, dmu2):
-        sh = ctx.sh
-        (idx_all,) = ctx.saved_tensors
-        d_all = sh.all_gather(dmu2.contiguous())
-        sink = ctx.sink
-        dshard = sink if sink is not None else torch.zeros(ctx.shape, device=dmu2.device, dtype=dmu2.dtype)
-        # the objective is the mean over ranks of the local losses: 1/W on every rank's contribution
-        sh.backend.scatter_rows_(dshard, d_all, idx_all, sh.row0, 1.0 / sh.world)
-        return (None if sink is not None else dshard), None, None
-
-
-class _ShardDisc(torch.autograd.Function):
-    """log-sum-exp cross-entropy of the local queries against the WHOLE (sharded) table; returns the mean
-    over the GLOBAL batch (identical on every rank) -- simple_fhvae.py:119-122."""
-
-    @staticmethod
-    def forward(ctx, q_local, shard, idx_all, sh: ShardCtx):
-        be = sh.backend
-        q_all = sh.all_gather(q_local.detach())
-        rmax, rsum, tgt = be.disc_partials(q_all, shard, idx_all, sh.row0)
-        m = rmax.clone()
-        sh.all_reduce_(m, op=dist.ReduceOp.MAX)
-        st = torch.stack([be.disc_rescale(rmax, rsum, m), tgt])
-        sh.all_reduce_(st)
-        ce = be.ce_mean(m, st[0].contiguous(), st[1].contiguous())
-        ctx.sh = sh
-        ctx.save_for_backward(q_all, shard, idx_all, m, st[0].contiguous())
-        return ce
-
-    @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, dmu2, g, _):
         sh, be = ctx.sh, ctx.sh.backend
         q_all, shard, idx_all, m, s = ctx.saved_tensors
-        g = g.reshape(1).contiguous()
-        n_all = q_all.shape[0]
+        n_all, D = q_all.shape
         n_loc = n_all // sh.world
-        dq_local = dshard = None
-        if ctx.needs_input_grad[0]:
-            # net gradients are averaged over ranks afterwards, so the query side carries W/B_global = 1/B_local
-            dq_all, _ = be.disc_bwd(q_all, shard, idx_all, sh.row0, m, s, g, 1.0 / n_loc, True, False)
-            dq_local = sh.reduce_scatter(dq_all)
-        if ctx.needs_input_grad[1]:
-            # the shard's gradient is complete locally (all global queries were scanned): true scale 1/B_global
-            _, dshard = be.disc_bwd(q_all, shard, idx_all, sh.row0, m, s, g, 1.0 / n_all, False, True)
+        need_dq, need_dt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dq_all = dshard = None
+        if g is not None and (need_dq or need_dt):
+            # one call for both sides (true scale 1/B_global: the shard's gradient is complete locally, all global queries were
+            # scanned); the query side is averaged over ranks with the net gradients afterwards, so it carries W/B_global
+            dq_all, dshard = be.disc_bwd(q_all, shard, idx_all, sh.row0, m, s, g.reshape(1).contiguous(), 1.0 / n_all, need_dq, need_dt)
+        # (4) [dq for all queries | dmu2 of the local queries in their rows], summed over the ranks
+        buf = q_all.new_zeros(n_all, 2 * D)
+        if dq_all is not None:
+            buf[:, :D] = dq_all * float(sh.world)
+        if dmu2 is not None:
+            buf[sh.rank * n_loc:(sh.rank + 1) * n_loc, D:] = dmu2
+        sh.all_reduce_(buf)
+        dq_local = buf[sh.rank * n_loc:(sh.rank + 1) * n_loc, :D].contiguous() if need_dq else None
+        if need_dt:
+            sink = ctx.sink
+            if sink is None:
+                sink = dshard if dshard is not None else q_all.new_zeros(ctx.shape)
+                dshard = sink
+            # the objective is the mean over ranks of the local losses: 1/W on every rank's mu2 contribution
+            be.scatter_rows_(sink, buf[:, D:].contiguous(), idx_all, sh.row0, 1.0 / sh.world)
         return dq_local, dshard, None, None
 
 
 class ShardedTableOps:
-    """Plugs into FHVAEBase (`model.table_ops`): same two calls as the single-GPU ops."""
+    """Plugs into FHVAEBase (`model.table_ops`): same calls as the single-GPU ops; the exchange happens in `resolve`."""
 
     def __init__(self, shard: nn.Parameter, sh: ShardCtx):
         self.shard, self.sh = shard, sh
-        self._idx_all = None
+        self._idx = None
 
     def lookup(self, mu_idx, num_seqs, mu2_table=None):
         if mu2_table is not None:
             raise ValueError("mu2_table injection is a single-GPU parity feature")
         if int(num_seqs) != self.sh.S:
             raise ValueError("num_seqs=%d does not match the sharded table (%d rows)" % (num_seqs, self.sh.S))
-        self._idx_all = self.sh.all_gather(mu_idx)
-        return self.shard, _ShardGather.apply(self.shard, self._idx_all, self.sh)
+        self._idx = mu_idx
+        return self.shard, None  # the rows arrive with the CE in resolve(): one exchange for both
 
-    def disc(self, z2_mu, table, mu_idx):
-        return _ShardDisc.apply(z2_mu, self.shard, self._idx_all, self.sh)
+    def resolve(self, z2_mu, table, mu_idx, mu2):
+        mu2, ce, _ = _ShardTable.apply(z2_mu, self.shard, self._idx if mu_idx is None else mu_idx, self.sh)
+        return mu2, ce
 
 
 class DistributedFHVAE:
@@ -210,13 +213,13 @@ class DistributedFHVAE:
         self.model = model
         self.sh = ShardCtx(model.mu2_table.shape[0], group, HipBackend())
         self.sh.backend.lp = getattr(model, "compute_dtype", "f32") == "bf16"
+        self.sh.backend.hb.reset_device_words(model.mu2_table.device)  # the sticky status words are per process: start clean
         full = model.mu2_table.data
         self.shard = nn.Parameter(full[self.sh.row0:self.sh.row1].clone())
         model.mu2_table = None  # the full table is dropped: only the shard stays resident
         model.table_ops = ShardedTableOps(self.shard, self.sh)
-        # Gradient buckets in the order their backward COMPLETES (decoder first, z2 encoder last): each bucket is
-        # contiguous in the flat arena, and its all-reduce is started (async, RCCL's own stream) as soon as the net's
-        # backward recurrence has been enqueued, i.e. it overlaps the next net's latency-bound backward cells (C1).
+        # Gradient buckets in the order their backward COMPLETES (decoder first, z2 encoder last): each bucket is contiguous
+        # in the flat arena; the first ones are reduced under the last net's weight-gradient launch (_on_lstm_rec_done).
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
 
         def group_of(name):
@@ -242,59 +245,49 @@ class DistributedFHVAE:
             for v in self.opt_nets.g_arena.views[k:k + c]:
                 self._bucket_of_ptr[v.data_ptr()] = g
             k += c
-        self._pending = {}
+        self._pending = None  # handle of the early all-reduce over the first buckets (False: it was synchronous)
         self.overlap = True
 
-    def _on_lstm_bwd_done(self, sinks):
-        """Fired by hip_binding at the end of an LSTM net's backward: that net's Gaussian head ran earlier in the
-        backward pass, so the whole bucket is final -> start its all-reduce now."""
-        import hip_binding as hb
-
-        # The persistent LSTM kernels need all 256 CUs co-resident: a collective kernel spinning on its peers next to
-        # them would hold some of those CUs for as long as the slowest rank takes.  With that schedule the buckets of the
-        # first two nets are reduced under the LAST net's weight-gradient contractions instead (_on_lstm_rec_done), where
-        # no persistent kernel follows before the optimizer.
-        if not self.overlap or not sinks or sinks[0] is None or hb.LAST_LSTM_FORM["form"] != 0:
-            return
-        g = self._bucket_of_ptr.get(sinks[0].data_ptr())
-        if g is None or g in self._pending:
-            return
-        b, e = self._buckets[g]
-        h = self.sh.all_reduce_(self.opt_nets.g_arena.flat[b:e], async_op=True)
-        self._pending[g] = h  # None when the transport was synchronous (staged gloo)
-
     def _on_lstm_rec_done(self, sinks):
-        """Fired by hip_binding between a net's backward recurrence and its parameter-gradient contractions.  Persistent
-        schedule only: once the LAST net's recurrence is enqueued, the finished buckets of the earlier nets (contiguous in
-        the arena) go out as one async all-reduce that overlaps this net's weight gradients and its head's backward."""
+        """Fired by hip_binding when a net's backward RECURRENCE has been enqueued (with deferred parameter gradients: queued
+        behind it).  Nets finish in bucket order.  When the second-to-last net (the z1 encoder) is through, the queued weight
+        gradients so far (decoder + z1 encoder) are flushed as one grouped launch; when the LAST net's recurrence is enqueued,
+        those buckets are complete and go out as ONE async all-reduce.  RCCL's stream waits for the work enqueued so far, i.e.
+        for the last persistent recurrence kernel of the step -- those need all 256 CUs co-resident, a collective kernel
+        spinning on its peers must not run beside them -- and the reduction then overlaps the last net's weight-gradient
+        launch (the second grouped launch, flushed by flat_grad()) and its head's backward."""
         import hip_binding as hb
 
-        if not self.overlap or not sinks or sinks[0] is None or hb.LAST_LSTM_FORM["form"] == 0:
+        if not self.overlap or not sinks or sinks[0] is None or self._pending is not None:
             return
         g = self._bucket_of_ptr.get(sinks[0].data_ptr())
         last = len(self._buckets) - 1
-        if g != last or self._pending or last < 1:
+        if g is None or last < 1:
             return
-        b, e = self._buckets[0][0], self._buckets[last - 1][1]
-        if e > b:
-            h = self.sh.all_reduce_(self.opt_nets.g_arena.flat[b:e], async_op=True)
-            for k in range(last):
-                self._pending[k] = h if k == 0 else None
+        if g == last - 1:
+            hb.flush_param_grads()
+        elif g == last:
+            hb.flush_param_grads_except_last()  # (no-op unless a net in between never fired: keeps the invariant explicit)
+            b, e = self._buckets[0][0], self._buckets[last - 1][1]
+            if e > b:
+                h = self.sh.all_reduce_(self.opt_nets.g_arena.flat[b:e], async_op=True)
+                self._pending = h if h is not None else False  # None: the transport was synchronous (staged gloo)
 
     def _reduce_gradients(self):
-        flat = self.opt_nets.flat_grad()
-        if not self._pending and self._buckets:  # nothing in flight: one collective over the contiguous buckets
+        flat = self.opt_nets.flat_grad()  # flushes the weight gradients still queued (the last net's: the second grouped launch)
+        if not self._buckets:
+            return
+        if self._pending is None:  # nothing went out early (FC model, overlap off): one collective over all buckets
             b, e = self._buckets[0][0], self._buckets[-1][1]
             if e > b:
                 self.sh.all_reduce_(flat[b:e])
             return
-        for g, (b, e) in enumerate(self._buckets):
-            if g in self._pending:
-                if self._pending[g] is not None:
-                    self._pending[g].wait()
-            elif e > b:
-                self.sh.all_reduce_(flat[b:e])
-        self._pending.clear()
+        b, e = self._buckets[-1]
+        if e > b:
+            self.sh.all_reduce_(flat[b:e])
+        if self._pending is not False:
+            self._pending.wait()
+        self._pending = None
 
     # -- checkpointing: the full table (and its Adam moments) exists only as row shards ----------------------------------
     def _gather_rows(self, local: torch.Tensor) -> torch.Tensor:
@@ -373,14 +366,12 @@ class DistributedFHVAE:
         self.opt_table.zero_grad()
         out = self.model(x, idx, self.sh.S, nsegs)
         loss = loss_function(out[0], out[1], alpha)
-        hb.LSTM_BWD_DONE_HOOK["fn"] = self._on_lstm_bwd_done
         hb.LSTM_BWD_REC_HOOK["fn"] = self._on_lstm_rec_done
         try:
             loss.backward()
         finally:
-            hb.LSTM_BWD_DONE_HOOK["fn"] = None
             hb.LSTM_BWD_REC_HOOK["fn"] = None
-        self._reduce_gradients()  # C1: three bucket all-reduces, two of them already in flight under the backward
+        self._reduce_gradients()  # C1: the decoder + z1 buckets are already in flight under the z2 encoder's weight gradients
         self.opt_nets.step()
         self.opt_table.step()
         return loss.detach(), out[0].detach()

@@ -30,6 +30,11 @@ class LocalTableOps:
     def disc(self, z2_mu, table, mu_idx):
         return hb.disc_lse(z2_mu, table, mu_idx, lp=getattr(self.model, "compute_dtype", "f32") == "bf16")
 
+    def resolve(self, z2_mu, table, mu_idx, mu2):
+        """(mu2 of the batch, CE against the whole table): the two things the loss tail needs from the table.  One call so that a
+        sharded table can serve both from ONE exchange (dist_shard.ShardedTableOps.resolve)."""
+        return mu2, self.disc(z2_mu, table, mu_idx)
+
 
 class FHVAEBase(nn.Module):
     """Common constructor surface and loss tail.
@@ -114,8 +119,8 @@ class FHVAEBase(nn.Module):
     def _tail(self, x_like, layout, x_mu, x_lv, z1, z2, mu2, table, mu_idx, num_segs):
         """simple_fhvae.py:105-124 on the HIP kernels."""
         rc = self.reference_compat
+        mu2, ce = self.table_ops.resolve(z2[0], table, mu_idx, mu2)
         lb, lpx, nk1, nk2, lpm = hb.elbo(x_like, x_mu, x_lv, z1[0], z1[1], z2[0], z2[1], mu2, num_segs, layout, rc)
-        ce = self.table_ops.disc(z2[0], table, mu_idx)
         log_qy = ce if rc else -ce
         self.qz2_x = [z2[0], z2[1]]      # read by estimate_mu2_dict, utils.py:52
         self.pz2 = [mu2, PZ2_LOGVAR]     # utils.py:58

@@ -87,6 +87,7 @@ SIGNATURES = {
     "fhvae_loss_bwd": (C.c_int, [_vp, _f32, _vp, _vp, _i64, _vp]),
     "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_form": (C.c_int, [C.POINTER(LstmDesc)]),
+    "fhvae_lstm_layout_id": (C.c_int, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_pre_elems": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_ws_below_elems": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
@@ -147,10 +148,9 @@ def load_library(path: str = LIB_PATH):
 _SIDE = {"stream": None, "pending": False, "keep": [], "enabled": False}
 
 
-#: optional callback(params_tuple) fired at the end of every _LstmSeq.backward: the data-parallel wrapper uses it to
-#: start the all-reduce of a net's gradient bucket while the next net's backward recurrence still runs
-LSTM_BWD_REC_HOOK = {"fn": None}  # fn(sinks): fired between a net's backward recurrence and its parameter gradients
-LSTM_BWD_DONE_HOOK = {"fn": None}
+#: optional callback(sinks) fired when a net's backward recurrence has been enqueued (its parameter gradients queued behind it, or
+#: about to run): the data-parallel wrapper flushes the queue / starts the gradient all-reduce of the finished buckets there
+LSTM_BWD_REC_HOOK = {"fn": None}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -176,6 +176,16 @@ def flush_param_grads():
     with _Timed("fhvae_lstm_param_grads_multi"):
         _check(lib.fhvae_lstm_param_grads_multi(arr, n, _stream()), "fhvae_lstm_param_grads_multi")
     pend.clear()  # (the caching allocator keeps the released buffers ordered behind this stream's queued work)
+
+
+def flush_param_grads_except_last():
+    """Flush every queued parameter-gradient phase but the most recent one (the net whose recurrence was just enqueued)."""
+    pend = _DEFER["pending"]
+    if len(pend) <= 1:
+        return
+    last = pend.pop()
+    flush_param_grads()
+    pend.append(last)
 
 
 def set_defer_param_grads(on: bool):
@@ -638,6 +648,7 @@ class _LstmSeq(torch.autograd.Function):
             _check(lib.fhvae_lstm_seq_fwd(C.byref(d), _stream()), "fhvae_lstm_seq_fwd")
         ctx.dims, ctx.dtype = dims, dtype
         ctx.x_lp = x_lp
+        ctx.layout_id = int(lib.fhvae_lstm_layout_id(C.byref(d)))  # the schedule this forward took (see backward)
         ctx.save_for_backward(x_tm, xc, hs, cs, gates, lp, *params)
         if top == 0:
             out = hn.new_empty(())  # placeholder (value never read): this net's per-step states are not an output
@@ -675,6 +686,9 @@ class _LstmSeq(torch.autograd.Function):
         for l in range(L):
             bd.dw_ih[l], bd.dw_hh[l], bd.db_ih[l], bd.db_hh[l] = (_p(grads[4 * l + k]) for k in range(4))
         bd.d_xc = _p(d_xc)
+        if int(lib.fhvae_lstm_layout_id(C.byref(d))) != ctx.layout_id:
+            raise RuntimeError("the LSTM schedule changed between this net's forward and its backward (an FHVAE_* switch was flipped "
+                               "in between?): the saved gates / workspaces are in the forward's layout")
         n_below = int(lib.fhvae_lstm_ws_below_elems(C.byref(d)))
         ws_below = torch.empty(n_below, **f32) if n_below > 0 else None
         bd.ws_below = _p(ws_below)
@@ -684,6 +698,8 @@ class _LstmSeq(torch.autograd.Function):
             with _Timed("fhvae_lstm_seq_bwd"):
                 _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
             _DEFER["pending"].append((bd, (x_tm, xc, hs, cs, gates, lp, pre, dgates, dgsum, dc, d_hs_top, d_hn, params, ctx.x_lp)))
+            if LSTM_BWD_REC_HOOK["fn"] is not None:  # the distributed runner decides when to flush the queue and start collectives
+                LSTM_BWD_REC_HOOK["fn"](ctx.sinks)
             return (None, d_xc, None, None, None, *[None] * len(params))
         if _SIDE["enabled"] and all(sk is not None for sk in ctx.sinks):
             # recurrence on this stream; the weight-gradient contractions on the side stream, joined by the optimizer
@@ -712,8 +728,6 @@ class _LstmSeq(torch.autograd.Function):
             bd.phase = 0
             with _Timed("fhvae_lstm_seq_bwd"):
                 _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
-        if LSTM_BWD_DONE_HOOK["fn"] is not None:
-            LSTM_BWD_DONE_HOOK["fn"](ctx.sinks)
         return (None, d_xc, None, None, None, *[None if sk is not None else g for g, sk in zip(grads, ctx.sinks)])
 
 

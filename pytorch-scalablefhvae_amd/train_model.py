@@ -117,6 +117,12 @@ def main(argv=None) -> int:
     from fhvae import FHVAE
     from simple_fhvae import SimpleFHVAE
 
+    import hip_binding as hb
+
+    # the sticky status words (divergence / a recurrence launch that gave up) are per process: a run starts clean.  After a run
+    # that returned 2 or 3 the model it trained is invalid (NaN updates may have been applied until the check interval caught them)
+    hb.reset_device_words(device)
+
     torch.manual_seed(args.seed)
     T, F = args.seg_len, args.mels
     real = args.train_feat_scp is not None
@@ -156,12 +162,27 @@ def main(argv=None) -> int:
         from utils import load_checkpoint_file
 
         ck_model, _values, optim_state, start_epoch, ck_best, _ = load_checkpoint_file(args.continue_from, False, input_size=input_size)
-        model.load_state_dict(ck_model.state_dict(), strict=True)
+        ck_sd = ck_model.state_dict()
+        ref_layout = "mu2_table" not in ck_sd  # a checkpoint of the reference itself: it never kept a table (simple_fhvae.py:51)
+        model.load_state_dict(ck_sd, strict=not ref_layout)
         if optim_state is not None:
+            if ref_layout:
+                # torch.optim.Adam's state over the reference's parameters (the nets, in named_parameters() order): ours has the
+                # table in front -> shift by one, the table's moments start fresh
+                n_have = len(optim_state["param_groups"][0]["params"])
+                n_nets = sum(1 for n, p in model.named_parameters() if p.requires_grad and n != "mu2_table")
+                if n_have != n_nets:
+                    raise ValueError("--continue-from: the checkpoint's optimizer holds %d parameters, this model's nets have %d"
+                                     % (n_have, n_nets))
+                names = [n for n, p in model.named_parameters() if p.requires_grad]
+                shift = 1 if names and names[0] == "mu2_table" else 0
+                grp = dict(optim_state["param_groups"][0], params=list(range(n_nets + shift)))
+                optim_state = {"state": {k + shift: v for k, v in optim_state["state"].items()}, "param_groups": [grp]}
             optimizer.load_state_dict(optim_state)
         if ck_best is not None:
             best_val_lb = float(ck_best)
-        best_epoch = start_epoch - 1
+        ck_raw = torch.load(args.continue_from, map_location="cpu", weights_only=False)
+        best_epoch = int(ck_raw.get("best_epoch", start_epoch - 1))  # the patience window continues where it stood
         print(f"resumed from {args.continue_from}: starting at epoch {start_epoch}")
 
     if real:

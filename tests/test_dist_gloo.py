@@ -89,10 +89,21 @@ def _worker(rank, world, port, ret):
     ops = ds.ShardedTableOps(shard, sh)
     sl = slice(rank * Bl, (rank + 1) * Bl)
     ql = enc(xg[sl])
-    _, mu2 = ops.lookup(idxg[sl].contiguous(), S)
-    ce = ops.disc(ql, None, None)
+    _, none = ops.lookup(idxg[sl].contiguous(), S)
+    assert none is None  # the rows arrive with the CE: ONE packed exchange (all-gather [q | idx], reduce-scatter rows, all-gather partials)
+    n_coll = {"n": 0}
+    for name in ("all_gather", "all_reduce_", "reduce_scatter"):
+        def wrap(fn):
+            def f(*a, **k):
+                n_coll["n"] += 1
+                return fn(*a, **k)
+            return f
+        setattr(sh, name, wrap(getattr(sh, name)))
+    mu2, ce = ops.resolve(ql, None, None, None)
+    fwd_coll = n_coll["n"]
     loss = -(mu2 * wv[sl] * ql).sum(1).mean() + alpha * ce
     loss.backward()
+    bwd_coll = n_coll["n"] - fwd_coll
     flat = torch.cat([p.grad.reshape(-1) for p in enc.parameters()])
     dist.all_reduce(flat)                   # C1, then 1/W (folded into Adam's grad_scale in the product)
     flat /= world
@@ -103,6 +114,8 @@ def _worker(rank, world, port, ret):
         "net_grads": torch.allclose(flat, ref_flat, rtol=1e-4, atol=1e-6),
         "shard_grads": torch.allclose(shard.grad, t_ref.grad[sh.row0:sh.row1], rtol=1e-4, atol=1e-6),
         "rows": (sh.row0, sh.row1),
+        # gloo has no reduce-scatter: ShardCtx emulates it with an all-reduce (one nested call) -> 3 (+1) forward, 1 backward
+        "collectives": (fwd_coll, bwd_coll),
     }
     ret[rank] = ok
     dist.destroy_process_group()
@@ -117,5 +130,8 @@ def test_sharded_table_two_ranks_gloo():
     assert ret[0]["rows"] == (0, 6) and ret[1]["rows"] == (6, 11)
     for r in range(world):
         for k, v in ret[r].items():
-            if k != "rows":
+            if k not in ("rows", "collectives"):
                 assert v, "rank %d: %s mismatch" % (r, k)
+        # packed exchange: forward = all-gather [q | idx] + reduce-scatter rows (gloo: emulated by an all-reduce inside it, counted
+        # twice) + all-gather partials; backward = ONE all-reduce [dq | dmu2]
+        assert ret[r]["collectives"] == (4, 1), ret[r]["collectives"]
