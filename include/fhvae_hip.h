@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 6
+#define FHVAE_ABI_VERSION 7
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -286,11 +286,20 @@ int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S);
 int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
                        float inv_two_var, float* row_max, float* row_sumexp, float* tgt_logit,
                        float* ce_mean, void* ws, int64_t B, int64_t S, int64_t D, int dtype, void* stream);
-/* Cross-shard combine helpers (multi-GPU): after an all-reduce(MAX) of row_max over the
- * shards, rescale a shard's sum to the global max:  out[b] = rsum_local[b] * exp(rmax_local[b] - m_global[b]);
- * after the all-reduce(SUM) of (out, tgt): ce = mean_b((m - tgt) + log s), single workgroup, deterministic. */
-int fhvae_disc_lse_rescale(const float* rmax_local, const float* rsum_local, const float* m_global,
-                           float* out, int64_t B, void* stream);
+/* Helpers of the row-sharded table's exchange (the reference has no distributed code): one launch each.
+ * pack / unpack: [q[b, 0..D) | int32 bits of idx[b]] rows of D+1 floats -- queries and row indices travel in one all-gather.
+ * merge_partials: the W ranks' K5 partials, parts[w] = [row_max | row_sumexp | tgt_logit] of N queries each, merged into the
+ *   global (row_max, row_sumexp, tgt_logit): max, sum of sumexp_w * exp(max_w - max), sum (log-sum-exp of simple_fhvae.py:122).
+ * bwd_pack / bwd_unpack: the backward's single all-reduce buffer, N x 2D: [dq_all * dq_scale | dmu2 of the n_own local queries
+ *   from row own0 on, zeros elsewhere]; unpack returns the local queries' dq and every query's dmu2 (either may be NULL). */
+int fhvae_shard_pack(const float* q, const int64_t* idx, float* out, int64_t B, int64_t D, void* stream);
+int fhvae_shard_unpack(const float* packed, float* q, int64_t* idx, int64_t N, int64_t D, void* stream);
+int fhvae_disc_merge_partials(const float* parts, float* row_max, float* row_sumexp, float* tgt_logit, int64_t W, int64_t N,
+                              void* stream);
+int fhvae_shard_bwd_pack(const float* dq_all, float dq_scale, const float* dmu2_local, int64_t own0, int64_t n_own, float* out,
+                         int64_t N, int64_t D, void* stream);
+int fhvae_shard_bwd_unpack(const float* buf, int64_t own0, int64_t n_own, float* dq_local, float* dmu2_all, int64_t N, int64_t D,
+                           void* stream);
 int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp, const float* tgt_logit,
                        float* ce_mean, int64_t B, void* stream);
 

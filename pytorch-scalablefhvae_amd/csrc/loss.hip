@@ -393,10 +393,68 @@ __global__ void loss_bwd_kernel(const float* __restrict__ g, float alpha, float*
   if (i == 0 && d_qy) d_qy[0] = -alpha * gv;
 }
 
-__global__ void disc_rescale_kernel(const float* __restrict__ rmax, const float* __restrict__ rsum,
-                                    const float* __restrict__ m, float* __restrict__ out, int64_t B) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) out[i] = rsum[i] * __expf(rmax[i] - m[i]);
+// ---- helpers of the row-sharded table's exchange (dist_shard.py): one launch each instead of 4-6 elementwise ATen launches
+// pack: out[b] = [q[b, 0..D) | bits of int32(idx[b])] -- the queries and their row indices travel in ONE all-gather
+__global__ void shard_pack_kernel(const float* __restrict__ q, const int64_t* __restrict__ idx, float* __restrict__ out, int64_t B, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * (D + 1)) return;
+  const int64_t b = i / (D + 1);
+  const int d = (int)(i - b * (D + 1));
+  out[i] = d < D ? q[b * D + d] : __int_as_float((int)idx[b]);
+}
+__global__ void shard_unpack_kernel(const float* __restrict__ pk, float* __restrict__ q, int64_t* __restrict__ idx, int64_t N, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * (D + 1)) return;
+  const int64_t b = i / (D + 1);
+  const int d = (int)(i - b * (D + 1));
+  if (d < D)
+    q[b * D + d] = pk[i];
+  else
+    idx[b] = (int64_t)__float_as_int(pk[i]);
+}
+// merge of the W ranks' K5 partials (parts[w] = [max | sumexp | target], N each): m = max_w, s = sum_w sumexp_w exp(max_w - m),
+// t = sum_w target_w.  An empty shard's (-inf, 0, 0) contributes exp(-inf) * 0 = 0.
+__global__ void disc_merge_kernel(const float* __restrict__ parts, float* __restrict__ m, float* __restrict__ s, float* __restrict__ t,
+                                  int W, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float mx = -INFINITY;
+  for (int w = 0; w < W; ++w) mx = fmaxf(mx, parts[((int64_t)w * 3 + 0) * N + i]);
+  float ss = 0.f, tt = 0.f;
+  for (int w = 0; w < W; ++w) {
+    const float rm = parts[((int64_t)w * 3 + 0) * N + i], rs = parts[((int64_t)w * 3 + 1) * N + i];
+    ss += rs > 0.f ? rs * __expf(rm - mx) : 0.f;
+    tt += parts[((int64_t)w * 3 + 2) * N + i];
+  }
+  m[i] = mx, s[i] = ss, t[i] = tt;
+}
+// backward buffer [dq * scale | dmu2 rows of the local queries (zeros elsewhere)], N x 2D
+__global__ void shard_bwd_pack_kernel(const float* __restrict__ dq, float scale, const float* __restrict__ dmu2, int64_t own0, int64_t nown,
+                                      float* __restrict__ out, int64_t N, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * 2 * D) return;
+  const int64_t b = i / (2 * D);
+  const int d = (int)(i - b * 2 * D);
+  float v = 0.f;
+  if (d < D) {
+    if (dq) v = dq[b * D + d] * scale;
+  } else if (dmu2 && b >= own0 && b < own0 + nown) {
+    v = dmu2[(b - own0) * D + (d - D)];
+  }
+  out[i] = v;
+}
+// ... and back: dq of the local queries, dmu2 of all queries (contiguous for the scatter)
+__global__ void shard_bwd_unpack_kernel(const float* __restrict__ buf, int64_t own0, int64_t nown, float* __restrict__ dq_local,
+                                        float* __restrict__ dmu2_all, int64_t N, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * 2 * D) return;
+  const int64_t b = i / (2 * D);
+  const int d = (int)(i - b * 2 * D);
+  if (d < D) {
+    if (dq_local && b >= own0 && b < own0 + nown) dq_local[(b - own0) * D + d] = buf[i];
+  } else if (dmu2_all) {
+    dmu2_all[b * D + (d - D)] = buf[i];
+  }
 }
 
 // Backward, query side: dq[b,:] = -2c * sum_s w_bs (q_b - t_s), w = g (p - onehot)
@@ -728,15 +786,53 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
   return e;
 }
 
-extern "C" int fhvae_disc_lse_rescale(const float* rmax_local, const float* rsum_local, const float* m_global, float* out,
-                                      int64_t B, void* stream) {
-  FH_CHECK_PTR(rmax_local);
-  FH_CHECK_PTR(rsum_local);
-  FH_CHECK_PTR(m_global);
+extern "C" int fhvae_shard_pack(const float* q, const int64_t* idx, float* out, int64_t B, int64_t D, void* stream) {
+  FH_CHECK_PTR(q);
+  FH_CHECK_PTR(idx);
   FH_CHECK_PTR(out);
   FH_CHECK_POS(B);
-  hipLaunchKernelGGL(disc_rescale_kernel, dim3((unsigned)fh_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, rmax_local,
-                     rsum_local, m_global, out, B);
+  FH_CHECK_POS(D);
+  hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned)fh_cdiv(B * (D + 1), 256)), dim3(256), 0, (hipStream_t)stream, q, idx, out, B, (int)D);
+  return fh_launch_status();
+}
+extern "C" int fhvae_shard_unpack(const float* packed, float* q, int64_t* idx, int64_t N, int64_t D, void* stream) {
+  FH_CHECK_PTR(packed);
+  FH_CHECK_PTR(q);
+  FH_CHECK_PTR(idx);
+  FH_CHECK_POS(N);
+  FH_CHECK_POS(D);
+  hipLaunchKernelGGL(shard_unpack_kernel, dim3((unsigned)fh_cdiv(N * (D + 1), 256)), dim3(256), 0, (hipStream_t)stream, packed, q, idx, N, (int)D);
+  return fh_launch_status();
+}
+extern "C" int fhvae_disc_merge_partials(const float* parts, float* row_max, float* row_sumexp, float* tgt_logit, int64_t W, int64_t N,
+                                         void* stream) {
+  FH_CHECK_PTR(parts);
+  FH_CHECK_PTR(row_max);
+  FH_CHECK_PTR(row_sumexp);
+  FH_CHECK_PTR(tgt_logit);
+  FH_CHECK_POS(W);
+  FH_CHECK_POS(N);
+  FH_CHECK_I32(W);
+  hipLaunchKernelGGL(disc_merge_kernel, dim3((unsigned)fh_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, parts, row_max, row_sumexp,
+                     tgt_logit, (int)W, N);
+  return fh_launch_status();
+}
+extern "C" int fhvae_shard_bwd_pack(const float* dq_all, float dq_scale, const float* dmu2_local, int64_t own0, int64_t n_own, float* out,
+                                    int64_t N, int64_t D, void* stream) {
+  FH_CHECK_PTR(out);
+  FH_CHECK_POS(N);
+  FH_CHECK_POS(D);
+  hipLaunchKernelGGL(shard_bwd_pack_kernel, dim3((unsigned)fh_cdiv(N * 2 * D, 256)), dim3(256), 0, (hipStream_t)stream, dq_all, dq_scale,
+                     dmu2_local, own0, n_own, out, N, (int)D);
+  return fh_launch_status();
+}
+extern "C" int fhvae_shard_bwd_unpack(const float* buf, int64_t own0, int64_t n_own, float* dq_local, float* dmu2_all, int64_t N, int64_t D,
+                                      void* stream) {
+  FH_CHECK_PTR(buf);
+  FH_CHECK_POS(N);
+  FH_CHECK_POS(D);
+  hipLaunchKernelGGL(shard_bwd_unpack_kernel, dim3((unsigned)fh_cdiv(N * 2 * D, 256)), dim3(256), 0, (hipStream_t)stream, buf, own0, n_own,
+                     dq_local, dmu2_all, N, (int)D);
   return fh_launch_status();
 }
 

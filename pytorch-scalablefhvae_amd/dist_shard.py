@@ -50,16 +50,31 @@ class HipBackend:
         self.hb.raw_scatter_rows_(dshard, drows, idx_all, row0, scale)
 
     def disc_partials(self, q_all, shard, idx_all, row0):
+        """(3, N): row_max, row_sumexp, tgt_logit of this shard for all queries."""
+        n = q_all.shape[0]
+        out = torch.empty(3, n, device=q_all.device, dtype=torch.float32)
         if shard.shape[0] == 0:
-            n = q_all.shape[0]
-            z = torch.zeros(n, device=q_all.device, dtype=torch.float32)
-            return torch.full_like(z, -float("inf")), z, z.clone()
-        rmax, rsum, tgt, _ = self.hb.raw_disc_fwd(q_all, shard, idx_all, row0=row0, want_ce=False, lp=self.lp)
-        return rmax, rsum, tgt
+            out[0].fill_(-float("inf"))
+            out[1:].zero_()
+            return out
+        self.hb.raw_disc_fwd(q_all, shard, idx_all, row0=row0, want_ce=False, lp=self.lp, out3=out)
+        return out
 
-    def disc_rescale(self, rmax, rsum, m):
-        # an empty shard's (-inf, 0) partial rescales to 0 * exp(-inf) = 0 in the kernel: no special case
-        return self.hb.raw_disc_rescale(rmax, rsum, m)
+    # the small elementwise steps of the exchange, one launch each (fhvae_shard_* / fhvae_disc_merge_partials)
+    def pack(self, q, idx):
+        return self.hb.shard_pack(q.detach().float().contiguous(), idx.contiguous())
+
+    def unpack(self, pk):
+        return self.hb.shard_unpack(pk)
+
+    def merge_partials(self, parts):
+        return self.hb.disc_merge_partials(parts)
+
+    def bwd_pack(self, dq_all, dq_scale, dmu2_local, own0, n_all, D):
+        return self.hb.shard_bwd_pack(dq_all, dq_scale, dmu2_local.contiguous() if dmu2_local is not None else None, own0, n_all, D)
+
+    def bwd_unpack(self, buf, own0, n_own, want_dq, want_dmu2):
+        return self.hb.shard_bwd_unpack(buf, own0, n_own, want_dq, want_dmu2)
 
     def ce_mean(self, m, s, tgt):
         return self.hb.raw_disc_ce_mean(m, s, tgt)
@@ -130,24 +145,17 @@ class _ShardTable(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_local, shard, idx_local, sh: ShardCtx):
         be = sh.backend
-        D = q_local.shape[1]
         # (1) one buffer: the queries and, in the last column, the row indices as int32 bit patterns
-        pk = torch.cat([q_local.detach().float(), idx_local.to(torch.int32).view(torch.float32).reshape(-1, 1)], dim=1)
-        pk_all = sh.all_gather(pk)
-        q_all = pk_all[:, :D].contiguous()
-        idx_all = pk_all[:, D].contiguous().view(torch.int32).to(torch.int64)
+        q_all, idx_all = be.unpack(sh.all_gather(be.pack(q_local, idx_local)))
         # (2) rows: zeros for rows owned elsewhere, so the sum over ranks is the row
         mu2 = sh.reduce_scatter(be.gather_rows(shard, idx_all, sh.row0))
-        # (3) K5 partials of this shard for ALL queries, merged locally
-        rmax, rsum, tgt = be.disc_partials(q_all, shard, idx_all, sh.row0)
-        parts = sh.all_gather(torch.stack([rmax, rsum, tgt], dim=1)).view(sh.world, -1, 3)
-        m = parts[:, :, 0].max(dim=0).values
-        s = (parts[:, :, 1] * torch.exp(parts[:, :, 0] - m)).sum(dim=0)  # (an empty shard's (-inf, 0) contributes exp(-inf) * 0 = 0)
-        t = parts[:, :, 2].sum(dim=0)
-        ce = be.ce_mean(m.contiguous(), s.contiguous(), t.contiguous())
+        # (3) K5 partials of this shard for ALL queries, merged locally (an empty shard's (-inf, 0) contributes nothing)
+        parts = sh.all_gather(be.disc_partials(q_all, shard, idx_all, sh.row0)).view(sh.world, 3, -1)
+        m, s, t = be.merge_partials(parts)
+        ce = be.ce_mean(m, s, t)
         ctx.sh, ctx.shape = sh, tuple(shard.shape)
         ctx.sink = getattr(shard, "_fh_grad", None)
-        ctx.save_for_backward(q_all, shard, idx_all, m.contiguous(), s.contiguous())
+        ctx.save_for_backward(q_all, shard, idx_all, m, s)
         ctx.mark_non_differentiable(idx_all)
         return mu2, ce, idx_all
 
@@ -164,20 +172,16 @@ class _ShardTable(torch.autograd.Function):
             # scanned); the query side is averaged over ranks with the net gradients afterwards, so it carries W/B_global
             dq_all, dshard = be.disc_bwd(q_all, shard, idx_all, sh.row0, m, s, g.reshape(1).contiguous(), 1.0 / n_all, need_dq, need_dt)
         # (4) [dq for all queries | dmu2 of the local queries in their rows], summed over the ranks
-        buf = q_all.new_zeros(n_all, 2 * D)
-        if dq_all is not None:
-            buf[:, :D] = dq_all * float(sh.world)
-        if dmu2 is not None:
-            buf[sh.rank * n_loc:(sh.rank + 1) * n_loc, D:] = dmu2
+        buf = be.bwd_pack(dq_all, float(sh.world), dmu2, sh.rank * n_loc, n_all, D)
         sh.all_reduce_(buf)
-        dq_local = buf[sh.rank * n_loc:(sh.rank + 1) * n_loc, :D].contiguous() if need_dq else None
+        dq_local, dmu2_all = be.bwd_unpack(buf, sh.rank * n_loc, n_loc, need_dq, need_dt)
         if need_dt:
             sink = ctx.sink
             if sink is None:
                 sink = dshard if dshard is not None else q_all.new_zeros(ctx.shape)
                 dshard = sink
             # the objective is the mean over ranks of the local losses: 1/W on every rank's mu2 contribution
-            be.scatter_rows_(sink, buf[:, D:].contiguous(), idx_all, sh.row0, 1.0 / sh.world)
+            be.scatter_rows_(sink, dmu2_all, idx_all, sh.row0, 1.0 / sh.world)
         return dq_local, dshard, None, None
 
 

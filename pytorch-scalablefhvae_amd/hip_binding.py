@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
 
 F32, BF16 = 0, 1
 MAX_LAYERS = 4
-ABI_VERSION = 6  # FHVAE_ABI_VERSION of include/fhvae_hip.h
+ABI_VERSION = 7  # FHVAE_ABI_VERSION of include/fhvae_hip.h
 #: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
 INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
@@ -97,7 +97,11 @@ SIGNATURES = {
     "fhvae_proj_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     "fhvae_mu2_gather_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp]),
-    "fhvae_disc_lse_rescale": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "fhvae_shard_pack": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "fhvae_shard_unpack": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "fhvae_disc_merge_partials": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "fhvae_shard_bwd_pack": (C.c_int, [_vp, _f32, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "fhvae_shard_bwd_unpack": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
     "fhvae_disc_ce_mean": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "fhvae_elbo_fwd": (C.c_int, [C.POINTER(ElboDesc), _vp]),
     "fhvae_elbo_bwd": (C.c_int, [C.POINTER(ElboBwdDesc), _vp]),
@@ -879,14 +883,15 @@ def fused_loss(lower_bound, log_qy, alpha):
     return _FusedLoss.apply(lower_bound, log_qy, float(alpha))
 
 
-def raw_disc_fwd(q, table, idx, row0=0, want_ce=True, lp=False):
-    """lp: the bf16 compute mode's kernels (split-operand bf16 MFMA) where they apply (D = 32, B*S >= 65536)."""
+def raw_disc_fwd(q, table, idx, row0=0, want_ce=True, lp=False, out3=None):
+    """lp: the bf16 compute mode's kernels (split-operand bf16 MFMA) where they apply (D = 32, B*S >= 65536).
+    out3: an optional (3, B) f32 buffer that receives (row_max, row_sumexp, tgt_logit) as its rows."""
     lib = load_library()
     B, D = q.shape
     S = table.shape[0]
     dev = q.device
     ws = torch.empty(max(int(lib.fhvae_disc_lse_ws_bytes(B, S)), 8), device=dev, dtype=torch.uint8)
-    rmax, rsum, tgt = (torch.empty(B, device=dev, dtype=torch.float32) for _ in range(3))
+    rmax, rsum, tgt = (out3[0], out3[1], out3[2]) if out3 is not None else (torch.empty(B, device=dev, dtype=torch.float32) for _ in range(3))
     ce = torch.empty((), device=dev, dtype=torch.float32) if want_ce else None
     with _Timed("fhvae_disc_lse_fwd"):
         _check(lib.fhvae_disc_lse_fwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(tgt), _p(ce), _p(ws),
@@ -906,13 +911,50 @@ def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True
     return dq, (None if dt_sink is not None else dt)
 
 
-def raw_disc_rescale(rmax_local, rsum_local, m_global):
+def shard_pack(q, idx):
+    """[q | int32 bits of idx] rows (fhvae_shard_pack)."""
     lib = load_library()
-    out = torch.empty_like(rsum_local)
-    with _Timed("fhvae_disc_lse_rescale"):
-        _check(lib.fhvae_disc_lse_rescale(_p(rmax_local), _p(rsum_local), _p(m_global), _p(out), out.numel(), _stream()),
-               "fhvae_disc_lse_rescale")
+    B, D = q.shape
+    out = torch.empty(B, D + 1, device=q.device, dtype=torch.float32)
+    _check(lib.fhvae_shard_pack(_p(q), _p(idx), _p(out), B, D, _stream()), "fhvae_shard_pack")
     return out
+
+
+def shard_unpack(pk):
+    lib = load_library()
+    N, D = pk.shape[0], pk.shape[1] - 1
+    q = torch.empty(N, D, device=pk.device, dtype=torch.float32)
+    idx = torch.empty(N, device=pk.device, dtype=torch.int64)
+    _check(lib.fhvae_shard_unpack(_p(pk), _p(q), _p(idx), N, D, _stream()), "fhvae_shard_unpack")
+    return q, idx
+
+
+def disc_merge_partials(parts):
+    """parts (W, 3, N) -> (row_max, row_sumexp, tgt_logit) of the whole table (fhvae_disc_merge_partials)."""
+    lib = load_library()
+    W, _, N = parts.shape
+    m, s, t = (torch.empty(N, device=parts.device, dtype=torch.float32) for _ in range(3))
+    _check(lib.fhvae_disc_merge_partials(_p(parts), _p(m), _p(s), _p(t), W, N, _stream()), "fhvae_disc_merge_partials")
+    return m, s, t
+
+
+def shard_bwd_pack(dq_all, dq_scale, dmu2_local, own0, n_all, D):
+    lib = load_library()
+    ref = dq_all if dq_all is not None else dmu2_local
+    out = torch.empty(n_all, 2 * D, device=ref.device, dtype=torch.float32)
+    n_own = dmu2_local.shape[0] if dmu2_local is not None else 0
+    _check(lib.fhvae_shard_bwd_pack(_p(dq_all), float(dq_scale), _p(dmu2_local), own0, n_own, _p(out), n_all, D, _stream()),
+           "fhvae_shard_bwd_pack")
+    return out
+
+
+def shard_bwd_unpack(buf, own0, n_own, want_dq=True, want_dmu2=True):
+    lib = load_library()
+    N, D = buf.shape[0], buf.shape[1] // 2
+    dq = torch.empty(n_own, D, device=buf.device, dtype=torch.float32) if want_dq else None
+    dm = torch.empty(N, D, device=buf.device, dtype=torch.float32) if want_dmu2 else None
+    _check(lib.fhvae_shard_bwd_unpack(_p(buf), own0, n_own, _p(dq), _p(dm), N, D, _stream()), "fhvae_shard_bwd_unpack")
+    return dq, dm
 
 
 def raw_disc_ce_mean(m, s, tgt):

@@ -38,10 +38,30 @@ class OracleBackend:
         ok = (rel >= 0) & (rel < shard.shape[0])
         tgt = torch.zeros_like(rmax)
         tgt[ok] = lg[ok, rel[ok]]
-        return rmax, rsum, tgt
+        return torch.stack([rmax, rsum, tgt])
 
-    def disc_rescale(self, rmax, rsum, m):
-        return rsum * torch.exp(rmax - m)
+    def pack(self, q, idx):
+        return torch.cat([q.detach().float(), idx.to(torch.int32).view(torch.float32).reshape(-1, 1)], dim=1)
+
+    def unpack(self, pk):
+        D = pk.shape[1] - 1
+        return pk[:, :D].contiguous(), pk[:, D].contiguous().view(torch.int32).to(torch.int64)
+
+    def merge_partials(self, parts):
+        m = parts[:, 0].max(dim=0).values
+        return m, (parts[:, 1] * torch.exp(parts[:, 0] - m)).sum(dim=0), parts[:, 2].sum(dim=0)
+
+    def bwd_pack(self, dq_all, dq_scale, dmu2_local, own0, n_all, D):
+        buf = torch.zeros(n_all, 2 * D)
+        if dq_all is not None:
+            buf[:, :D] = dq_all * dq_scale
+        if dmu2_local is not None:
+            buf[own0:own0 + dmu2_local.shape[0], D:] = dmu2_local
+        return buf
+
+    def bwd_unpack(self, buf, own0, n_own, want_dq, want_dmu2):
+        D = buf.shape[1] // 2
+        return (buf[own0:own0 + n_own, :D].contiguous() if want_dq else None), (buf[:, D:].contiguous() if want_dmu2 else None)
 
     def ce_mean(self, m, s, tgt):
         return ((m - tgt) + torch.log(s)).mean()

@@ -29,16 +29,21 @@ def test_disc_translation_invariance_and_shard_associativity(hb, B, S):
     # three row shards combine to the unsharded (max, sumexp, target)
     rmax, rsum, tgt, _ = hb.raw_disc_fwd(q.detach(), t.detach(), idx, want_ce=False)
     cuts = [0, S // 3, S // 3 + 1, S]
-    ms, ss, tg = [], [], []
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        m_, s_, t_, _ = hb.raw_disc_fwd(q.detach(), t.detach()[a:b].contiguous(), idx, row0=a, want_ce=False)
-        ms.append(m_), ss.append(s_), tg.append(t_)
-    m = torch.stack(ms).max(0).values
-    s = sum(hb.raw_disc_rescale(mi, si, m) for mi, si in zip(ms, ss))
+    parts = torch.empty(len(cuts) - 1, 3, q.shape[0], device="cuda")  # what the ranks all-gather (dist_shard._ShardTable)
+    for w, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        hb.raw_disc_fwd(q.detach(), t.detach()[a:b].contiguous(), idx, row0=a, want_ce=False, out3=parts[w])
+    m, s, tg = hb.disc_merge_partials(parts)
     close(m, rmax, rtol=1e-6, what="combined max")
     close(torch.log(s) + m, torch.log(rsum) + rmax, rtol=1e-5, what="combined lse")
-    close(sum(tg), tgt, rtol=1e-5, what="combined target logit")
-    close(hb.raw_disc_ce_mean(m, s, sum(tg)), ce.detach(), rtol=1e-5, what="combined CE")
+    close(tg, tgt, rtol=1e-5, what="combined target logit")
+    close(hb.raw_disc_ce_mean(m, s, tg), ce.detach(), rtol=1e-5, what="combined CE")
+    # the exchange's pack / unpack round trips (indices as int32 bit patterns beside the f32 queries)
+    q2, i2 = hb.shard_unpack(hb.shard_pack(q.detach(), idx))
+    assert torch.equal(q2, q.detach()) and torch.equal(i2, idx)
+    dq, dm = torch.randn(q.shape[0], q.shape[1], device="cuda"), torch.randn(100, q.shape[1], device="cuda")
+    buf = hb.shard_bwd_pack(dq, 2.0, dm, 50, q.shape[0], q.shape[1])
+    dql, dma = hb.shard_bwd_unpack(buf, 50, 100)
+    assert torch.equal(dql, dq[50:150] * 2.0) and torch.equal(dma[50:150], dm) and float(dma[:50].abs().sum() + dma[150:].abs().sum()) == 0.0
 
 
 def test_elbo_additivity_fullsize(hb):
