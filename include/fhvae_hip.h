@@ -76,6 +76,12 @@ int fhvae_gauss_head_reparam_fwd(const void* h, int64_t ldh, const void* w_mu, c
                                  const float* b_mu, const float* b_lv, const float* eps, float* mu,
                                  float* logvar, float* sample, int64_t M, int64_t K, int64_t D,
                                  int dtype, void* stream);
+/* mu | logvar of a Gaussian head WITHOUT sampling (the decoder's per-frame head, simple_fhvae.py:98-103, :211-213) as ONE
+ * projection over the M = T*B rows: h_lp [M,K] bf16, w_pair_lp = the two bf16 weight matrices stacked [2D,K]; out[M, 2D] f32 (row
+ * stride ldo): mu in columns [0,D), logvar in [D,2D). */
+int fhvae_gauss_head_pair_fwd(const void* h_lp, int64_t ldh, const void* w_pair_lp, const float* b_mu, const float* b_lv,
+                              float* out, int64_t ldo, int64_t M, int64_t K, int64_t D, void* stream);
+
 /* Elementwise part of the head's backward: given upstream d_mu, d_logvar, d_sample (any may be
  * NULL = zero) produce the gradients w.r.t. the two linear outputs:
  *   g_mu = d_mu + d_sample ; g_lv = d_logvar + d_sample * eps * 0.5 * exp(0.5*logvar)

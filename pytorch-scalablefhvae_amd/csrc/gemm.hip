@@ -3,6 +3,7 @@
 // Reference ops replaced: nn.Linear (+ReLU) at simple_fhvae.py:127-134 and the Gaussian layer at
 // simple_fhvae.py:193-216.
 #include "gemm_launch.h"
+#include "proj.h"
 
 #include <cstdlib>
 
@@ -655,6 +656,33 @@ extern "C" int fhvae_gauss_head_reparam_fwd(const void* h, int64_t ldh, const vo
     return fh_launch_status();
   }
   return FHVAE_OK;
+}
+
+// mu | logvar of a Gaussian head WITHOUT sampling (the per-frame decoder head, simple_fhvae.py:98-103) as ONE projection: the two
+// bf16 weight matrices stacked [2D, K], the outputs side by side in out[M, 2D] (mu = columns [0, D), logvar = [D, 2D))
+extern "C" int fhvae_gauss_head_pair_fwd(const void* h_lp, int64_t ldh, const void* w_pair_lp, const float* b_mu, const float* b_lv,
+                                         float* out, int64_t ldo, int64_t M, int64_t K, int64_t D, void* stream) {
+  FH_CHECK_PTR(h_lp);
+  FH_CHECK_PTR(w_pair_lp);
+  FH_CHECK_PTR(out);
+  FH_CHECK_POS(M);
+  FH_CHECK_POS(K);
+  FH_CHECK_POS(D);
+  FH_CHECK_I32(M);
+  hipStream_t st = (hipStream_t)stream;
+  if (proj_eligible(h_lp, ldh, w_pair_lp, K, out, ldo, M, 2 * D, K) && D % 4 == 0)
+    return launch_proj(h_lp, ldh, w_pair_lp, K, out, ldo, b_mu, M, 2 * D, K, st, b_lv, (int)D);
+  GemmParams ps[2] = {};  // shapes the projection kernel does not take: the generic engine, one grouped launch
+  for (int i = 0; i < 2; ++i) {
+    ps[i].seg[0] = Seg{h_lp, ldh, 1, (const u16*)w_pair_lp + (int64_t)i * D * K, K, 1, (int)K, 0};
+    ps[i].M = (int)M;
+    ps[i].N = (int)D;
+    ps[i].C = out + i * D;
+    ps[i].ldc = ldo;
+    ps[i].bias = i == 0 ? b_mu : b_lv;
+    ps[i].splitk = 1;
+  }
+  return launch_gemm_group(ps, 2, FHVAE_BF16, st);
 }
 
 extern "C" int fhvae_gauss_reparam_bwd(const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,

@@ -30,7 +30,9 @@ struct ProjArgs {
   const u16* A;
   const u16* B;
   float* C;
-  const float* bias;
+  const float* bias;   // [N] or NULL
+  const float* bias2;  // columns >= bias_split take bias2[n - bias_split] (two heads side by side); NULL: one vector
+  int bias_split;
   int64_t lda, ldb, ldc;
   int M, N, K;
 };
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kPjThreads) void proj_kernel(ProjArgs p) {
     const int n = n0 + wn * (BN / 4) + tn * 16 + 4 * q;
     if (n >= p.N) continue;  // (N % 4 == 0, host-checked)
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *(const f32x4*)(p.bias + n);
+    if (p.bias) bv = (p.bias2 && n >= p.bias_split) ? *(const f32x4*)(p.bias2 + (n - p.bias_split)) : *(const f32x4*)(p.bias + n);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m0 + wm * (BM / 2) + tm * 16 + r;
@@ -188,9 +190,9 @@ bool proj_eligible(const void* a, int64_t lda, const void* b, int64_t ldb, const
 }
 
 int launch_proj(const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc, const float* bias, int64_t M,
-                int64_t N, int64_t K, hipStream_t st) {
-  if (!proj_eligible(a, lda, b, ldb, c, ldc, M, N, K)) return FHVAE_ERR_ALIGN;
-  ProjArgs p = {(const u16*)a, (const u16*)b, c, bias, lda, ldb, ldc, (int)M, (int)N, (int)K};
+                int64_t N, int64_t K, hipStream_t st, const float* bias2, int bias_split) {
+  if (!proj_eligible(a, lda, b, ldb, c, ldc, M, N, K) || (bias2 && (bias_split % 4))) return FHVAE_ERR_ALIGN;
+  ProjArgs p = {(const u16*)a, (const u16*)b, c, bias, bias2, bias_split, lda, ldb, ldc, (int)M, (int)N, (int)K};
   const int BN = N > 128 ? 256 : 128;
   const int64_t ncol = fh_cdiv(N, BN);
   // the row tile that fills the chip's 256 CUs in the fewest rounds with the least padding: one round if it can
@@ -217,5 +219,5 @@ extern "C" int fhvae_proj_bf16(const void* a, int64_t lda, const void* b, int64_
   FH_CHECK_POS(N);
   FH_CHECK_POS(K);
   FH_CHECK_I32(M);
-  return launch_proj(a, lda, b, ldb, c, ldc, bias, M, N, K, (hipStream_t)stream);
+  return launch_proj(a, lda, b, ldb, c, ldc, bias, M, N, K, (hipStream_t)stream, nullptr, 0);
 }

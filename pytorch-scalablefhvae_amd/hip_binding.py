@@ -80,6 +80,7 @@ SIGNATURES = {
                                    _i64, C.c_int, C.c_int, _vp]),
     "fhvae_gauss_head_reparam_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int,
                                                _vp]),
+    "fhvae_gauss_head_pair_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "fhvae_gauss_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fhvae_gauss_head_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_gauss_head_bwd_lp": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
@@ -461,13 +462,21 @@ class _GaussHeadLp(torch.autograd.Function):
         wt = torch.empty(2, K, D, device=dev, dtype=torch.bfloat16)     # ... and their transposes (backward's KC operands)
         for i, w in enumerate((w_mu, w_lv)):
             _check(lib.fhvae_cast_bf16(_p(w), _p(wl[i]), _p(wt[i]), D, K, _stream()), "fhvae_cast_bf16")
-        mu = torch.empty(M, D, device=dev, dtype=torch.float32)
-        lv = torch.empty_like(mu)
         eps = _f32c(eps) if eps is not None else None
-        smp = torch.empty_like(mu) if eps is not None else None
-        with _Timed("fhvae_gauss_head_reparam_fwd"):
-            _check(lib.fhvae_gauss_head_reparam_fwd(_p(h_lp), K, _p(wl[0]), _p(wl[1]), _p(b_mu), _p(b_lv), _p(eps), _p(mu), _p(lv),
-                                                    _p(smp), M, K, D, BF16, _stream()), "fhvae_gauss_head_reparam_fwd")
+        if eps is None:
+            # no sampling (the per-frame decoder head): mu | logvar side by side from ONE projection over the stacked weights
+            out = torch.empty(M, 2 * D, device=dev, dtype=torch.float32)
+            with _Timed("fhvae_gauss_head_reparam_fwd"):
+                _check(lib.fhvae_gauss_head_pair_fwd(_p(h_lp), K, _p(wl), _p(b_mu), _p(b_lv), _p(out), 2 * D, M, K, D, _stream()),
+                       "fhvae_gauss_head_pair_fwd")
+            mu, lv, smp = out[:, :D], out[:, D:], None
+        else:
+            mu = torch.empty(M, D, device=dev, dtype=torch.float32)
+            lv = torch.empty_like(mu)
+            smp = torch.empty_like(mu)
+            with _Timed("fhvae_gauss_head_reparam_fwd"):
+                _check(lib.fhvae_gauss_head_reparam_fwd(_p(h_lp), K, _p(wl[0]), _p(wl[1]), _p(b_mu), _p(b_lv), _p(eps), _p(mu), _p(lv),
+                                                        _p(smp), M, K, D, BF16, _stream()), "fhvae_gauss_head_reparam_fwd")
         ctx.save_for_backward(h_lp, wt, eps, lv)
         if smp is None:
             smp = mu.new_empty(())  # placeholder (value never read)
@@ -808,7 +817,16 @@ class _Elbo(torch.autograd.Function):
         ctx.set_materialize_grads(False)  # the loss uses lower_bound only; the four reporting outputs carry no gradient
         lib = load_library()
         B, T, F_, xs, xos = layout
-        ts = [_f32c(t) for t in (x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2)]
+        # mu | logvar side by side in one (rows, 2F) buffer (the per-frame head's single projection): read in place through the
+        # row stride, and the backward writes its two gradients side by side too
+        pair = (x_mu.dim() == 2 and x_lv.dim() == 2 and x_mu.dtype == torch.float32 and x_lv.dtype == torch.float32
+                and x_mu.stride(1) == 1 and x_lv.stride(1) == 1 and x_mu.stride(0) == 2 * F_ and x_lv.stride(0) == 2 * F_
+                and x_lv.data_ptr() - x_mu.data_ptr() == 4 * F_ and xos == (F_, B * F_))
+        if pair:
+            xos = (2 * F_, B * 2 * F_)
+            layout = (B, T, F_, xs, xos)
+        ts = [t if (pair and i in (1, 2)) else _f32c(t) for i, t in enumerate((x, x_mu, x_lv, z1_mu, z1_lv, z2_mu, z2_lv, mu2))]
+        ctx.pair = pair
         if isinstance(num_segs, torch.Tensor):
             num_segs = num_segs.to(device=ts[0].device, dtype=torch.int64).contiguous()
         outs = [torch.empty(B, device=ts[0].device, dtype=torch.float32) for _ in range(5)]
@@ -837,8 +855,12 @@ class _Elbo(torch.autograd.Function):
         bd.g_lower_bound, bd.g_log_px_z, bd.g_neg_kld_z1, bd.g_neg_kld_z2, bd.g_log_pmu2 = (_p(g) for g in gs)
         bd.reference_detach = int(ctx.detach)
         need_x = not ctx.detach
-        d_xmu = torch.empty_like(ts[1]) if need_x else None
-        d_xlv = torch.empty_like(ts[2]) if need_x else None
+        if need_x and ctx.pair:
+            dbuf = torch.empty(ts[1].shape[0], 2 * F_, device=ts[1].device, dtype=torch.float32)
+            d_xmu, d_xlv = dbuf[:, :F_], dbuf[:, F_:]
+        else:
+            d_xmu = torch.empty_like(ts[1]) if need_x else None
+            d_xlv = torch.empty_like(ts[2]) if need_x else None
         dz = [torch.empty_like(t) for t in ts[3:8]]
         bd.d_x_mu, bd.d_x_lv = _p(d_xmu), _p(d_xlv)
         bd.d_z1_mu, bd.d_z1_lv, bd.d_z2_mu, bd.d_z2_lv, bd.d_mu2 = (_p(t) for t in dz)
