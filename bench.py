@@ -174,10 +174,10 @@ def cpu_baseline(cfg, dtype, budget_s=45.0, sample_B=256):
         fit = int(budget_s / t_one)
         n_timed = max(3, min(10, fit - 1))
         n_warm = max(2, min(5, 2 + fit - n_timed))
-    times = []
+    times, terms = [], {}
     for k in range(2, n_warm + n_timed):
         t0 = time.perf_counter()
-        _, lb = R.train_step(m, opt, table, x, idx, ns, *eps[k])
+        _, lb = R.train_step(m, opt, table, x, idx, ns, *eps[k], terms=terms if k == n_warm + n_timed - 1 else None)
         dt = time.perf_counter() - t0
         if k >= n_warm:
             times.append(dt)
@@ -187,7 +187,7 @@ def cpu_baseline(cfg, dtype, budget_s=45.0, sample_B=256):
            "median_ms": med * 1e3, "warmup_steps": n_warm, "timed_steps": len(times), "cpu_model": info["cpu_model"],
            "socket_physical_cores": info["socket_physical_cores"], "sockets": info["sockets"],
            "cgroup_cpu_quota": info["cgroup_cpu_quota"], "pinned_cpus": len(info["pin"]), "dtype": "f32",
-           "elbo_nats_per_frame": (lb.mean() / T).item(), "elbo_after_steps": n_steps,
+           "elbo_nats_per_frame": (lb.mean() / T).item(), "elbo_after_steps": n_steps, "terms": terms,
            "sample": "%d+%d full training steps (fwd+loss+bwd+Adam, median of the timed ones) of the torch-CPU oracle %s on the first "
                      "%d segments of the seeded batch (seeds 1234/1235/1236), full %d-row table with the reference's (B,S,D) "
                      "materialisation, fp32, %d threads pinned to one socket"
@@ -226,6 +226,10 @@ def cpu_baseline(cfg, dtype, budget_s=45.0, sample_B=256):
                 loss_function(out[0], out[1], 10.0).backward()
                 gopt.step()
             e = (out[0].mean() / T).item()
+            # every term of the last forward (batch means, nats per segment) beside the oracle's, and the worst relative difference
+            gt = {n: o.detach().mean().item() for n, o in zip(R.TERM_NAMES, out)}
+            rec["gpu_%s_terms" % leg] = gt
+            rec["gpu_%s_terms_max_rel_diff" % leg] = max(abs(gt[n] - terms[n]) / max(abs(terms[n]), 1.0) for n in terms) if terms else None
             rec["gpu_%s_elbo_nats_per_frame" % leg] = e
             rec["gpu_%s_elbo_rel_diff" % leg] = abs(e - rec["elbo_nats_per_frame"]) / abs(rec["elbo_nats_per_frame"])
             del gm, gopt, out

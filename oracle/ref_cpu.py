@@ -342,12 +342,18 @@ def fill_state_dict_det(model: nn.Module, seed: float = 1.0) -> None:
 # ---------------------------------------------------------------------------------------------
 # one full training step on CPU (used by bench.py's cpu_baseline leg and by trajectory tests)
 # ---------------------------------------------------------------------------------------------
-def train_step(model, opt, table, x, mu_idx, num_segs, eps_z2, eps_z1, alpha=10.0, reference_compat=False):
-    """zero_grad -> forward -> loss_function -> backward -> Adam step (train_model.py:446-454)."""
+TERM_NAMES = ("lower_bound", "log_qy", "log_px_z", "neg_kld_z1", "neg_kld_z2", "log_pmu2")  # fhvae.py:185 return order
+
+
+def train_step(model, opt, table, x, mu_idx, num_segs, eps_z2, eps_z1, alpha=10.0, reference_compat=False, terms=None):
+    """zero_grad -> forward -> loss_function -> backward -> Adam step (train_model.py:446-454).  `terms`: a dict that
+    receives the batch mean of every term the forward returned (TERM_NAMES)."""
     opt.zero_grad(set_to_none=True)
     out = model(x, mu_idx, table.shape[0], num_segs, mu2_table=table, eps_z2=eps_z2, eps_z1=eps_z1,
                 reference_compat=reference_compat)
     loss = loss_function(out[0], out[1], alpha)
     loss.backward()
     opt.step()
+    if terms is not None:
+        terms.update({n: o.detach().mean().item() for n, o in zip(TERM_NAMES, out)})
     return loss.detach(), out[0].detach()

@@ -282,7 +282,7 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t st) {
   // long-K bf16 weight gradients (KM/KM, K = T*B >= 16384): 128x64 tiles with 128-k panels (a third less operand traffic per
   // FLOP than 64x64; 56 KB of LDS = two workgroups per CU) and exactly as many K slices as fill the chip twice over
   // (512 workgroups).  1024x256 over K = 40960: 52 -> 43 us; other slice counts were slower (256: -6 %, 768: -4 % per step).
-  if (bf && want_auto && ktot >= 16384 && p.M >= 128 && p.seg[1].K == 0 && !p.seg[0].a_kc && !p.seg[0].b_kc && !getenv("FHVAE_NO_12864")) {
+  if (bf && want_auto && ktot >= 16384 && p.M >= 128 && p.seg[1].K == 0 && !p.seg[0].a_kc && !p.seg[0].b_kc) {
     const int64_t tiles = fh_cdiv(p.M, 128) * fh_cdiv(p.N, 64);
     int64_t sk = fh_cdiv(512, tiles);
     const int64_t panels = fh_cdiv(ktot, 128);

@@ -607,10 +607,9 @@ static int lstm_fwd_impl(const fhvae_lstm_desc* d, const Ops<T>& op, hipStream_t
     const int ts = trace_begin(st, kTraceFwdCell, fl);
     // large tiles (half the L2 -> LDS operand bytes per FLOP) only pay once they still give >= 2 workgroups per CU (see
     // gemm.hip): B >= 16384 at H = 256, B >= 2048 at H = 512 (configs[3]: 2048 workgroups of 64x64 pulled 14 TB/s from L2)
-    static const int fwd_tile = getenv("FHVAE_FWD_TILE") ? atoi(getenv("FHVAE_FWD_TILE")) : 0;
     // (measured at B = 2048, H = 512, bf16: 128x128 tiles 1.3-1.8 ms per net forward against 1.0-1.3 ms with 64x64: the
-    //  heuristic stays "B >= 16384"; FHVAE_FWD_TILE overrides for experiments)
-    const bool big_fwd = fwd_tile ? fwd_tile == 128 : B >= 16384;
+    //  heuristic stays "B >= 16384")
+    const bool big_fwd = B >= 16384;
     if (big_fwd) {
       dim3 grid((unsigned)fh_cdiv(B, 128), (unsigned)fh_cdiv(H, 32), (unsigned)nj);
       hipLaunchKernelGGL((lstm_fwd_step_kernel<T, 128, 128, 2, 2, 16>), grid, dim3(kThreads), 0, st, jobs);
@@ -781,9 +780,8 @@ static int lstm_bwd_impl(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStr
     const int ts = trace_begin(st, kTraceBwdCell, fl);
     // tile by how many workgroups the shape offers (>= 2 per CU wanted): 128x64 from B = 16384 at H = 256, 64x64 from
     // B = 2048 at H = 512 (32x32 tiles there: 2048 workgroups re-reading 1 GB of operand panels per launch from L2)
-    static const int bwd_tile = getenv("FHVAE_BWD_TILE") ? atoi(getenv("FHVAE_BWD_TILE")) : 0;
     // (measured at B = 2048, H = 512, bf16: 64x64 tiles 2.4 ms per net backward, 32x32 2.2-2.3 ms: no gain from larger tiles)
-    const int bt = bwd_tile ? bwd_tile : (B >= 16384 ? 128 : 32);
+    const int bt = B >= 16384 ? 128 : 32;
     if (bt == 128) {
       dim3 grid((unsigned)fh_cdiv(B, 128), (unsigned)fh_cdiv(H, 64), (unsigned)nj);
       hipLaunchKernelGGL((lstm_bwd_step_kernel<T, 128, 64, 4, 1, 16>), grid, dim3(kThreads), 0, st, jobs);

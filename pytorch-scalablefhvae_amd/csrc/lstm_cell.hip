@@ -53,8 +53,7 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
   end1 = end0 + (segs[1].K + BK - 1) / BK;
   end2 = end1 + (segs[2].K + BK - 1) / BK;
   end3 = end2 + (segs[3].K + BK - 1) / BK;
-  const int dbg = jobs.glds;  // FHVAE_CELL_DBG (timing ablations; wrong results): 1 no K loop, 2 no epilogue, 4 no stores
-  const int nsteps = (dbg & 1) ? 0 : end3;
+  const int nsteps = end3;
   // image row of this lane's piece q: (wave * 4 + q) * 8 + (lane >> 3); logical chunk c8 lands in physical chunk lane & 7.
   // Weight rows: image row j = wn' * 64 + g * 16 + i'  <->  row g * H + u0 + wn' * 16 + i' of W, i.e. piece q adds
   // (q >> 1) * H + (q & 1) * 8 rows to piece 0's
@@ -93,10 +92,6 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
     if (part != 0) cell_issue<4>(stg + BM * 128, b, xb, 0u, wave);
   };
   cell_mainloop<T, BM, RB, NS>(acc, nsteps, issue, st0, st1, st2, st3);
-  if (dbg & 2) {
-    if (acc[0][0][0] == 123.456f) J.c_out[0] = 0.f;
-    return;
-  }
 
   // Epilogue through LDS: the accumulators (one lane = i,f,g,o of a (row, unit): 16 lanes x 4 B runs) go to an f32 image
   // X[row][gate][32 units] (512 B per row; rows 0..63 in st0, 64..127 in st1), then every lane takes (row, 8 consecutive
@@ -160,7 +155,6 @@ __global__ __launch_bounds__(kCellThreads, NS <= 2 ? 2 : 1) void cell_fwd_kernel
       h[e] = og[e] * tanhf_(c[e]);
     }
     const unsigned o = row * uH + u;
-    if ((dbg & 4) && c[0] != 123.456f) continue;
     st8(J.c_out + o, c);
     st8t(J.h_out + o, h);
     if (J.h_out_f32) st8(J.h_out_f32 + o, h);
@@ -213,8 +207,6 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
   }
   sg.n0 = J.seg[0].K / BK;
   sg.n = sg.n0 + J.seg[1].K / BK;
-  const int dbg = jobs.glds;
-  if (dbg & 1) sg.n = sg.n0 = 0;
 
   f32x4 acc[TM][2];
 #pragma unroll
@@ -235,10 +227,6 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
     if (part != 0) cell_issue<2>(stg + BM * 128, rb, xb, kb, wave);
   };
   cell_mainloop<T, BM, BN, NS>(acc, sg.n, issue, st0, st1, st2, st3);
-  if (dbg & 2) {
-    if (acc[0][0][0] == 123.456f) J.dc[0] = 0.f;
-    return;
-  }
 
   // Epilogue through LDS (see the forward cell): dh -> X[row][64 units] f32 (256 B per row; the rows of wave row wm in
   // st<wm>), slot s of a row at s ^ swz(row); then (row, 8 units) items per lane with 16-byte global accesses.  Absent optional
@@ -310,7 +298,6 @@ __global__ __launch_bounds__(kCellThreads, (BM + 64) * 128 * NS <= 80 * 1024 ? 2
       dp[2][e] = d_g * (1.f - gg[e] * gg[e]);
       dp[3][e] = d_o * og[e] * (1.f - og[e]);
     }
-    if ((dbg & 4) && dcn[0] != 123.456f) continue;
     st8(J.dc + o, dcn);
 #pragma unroll
     for (int g = 0; g < 4; ++g) st8t(J.dg_out + o4 + g * uH, dp[g]);
@@ -385,34 +372,19 @@ bool cell_bwd_big_ok(const BwdJobs<T>& jobs, int nj) {
 
 template <typename T>
 int launch_cell_fwd_big(const FwdJobs<T>& jobs, int nj, hipStream_t st) {
-  static const int ns = getenv("FHVAE_CELL_FWD_NS") ? atoi(getenv("FHVAE_CELL_FWD_NS")) : 2;
-  static const int dbg = getenv("FHVAE_CELL_DBG") ? atoi(getenv("FHVAE_CELL_DBG")) : 0;
   FwdJobs<T> jd = jobs;
-  jd.glds = dbg;
+  jd.glds = 0;
   const dim3 grid((unsigned)(jobs.B / 128), (unsigned)(jobs.H / 32), (unsigned)nj), block(kCellThreads);
-  if (ns == 3)
-    hipLaunchKernelGGL((cell_fwd_kernel<T, 3>), grid, block, 0, st, jd);
-  else
-    hipLaunchKernelGGL((cell_fwd_kernel<T, 2>), grid, block, 0, st, jd);
+  hipLaunchKernelGGL((cell_fwd_kernel<T, 2>), grid, block, 0, st, jd);  // (two ring stages; three measured no faster)
   return fh_launch_status();
 }
 
 template <typename T>
 int launch_cell_bwd_big(const BwdJobs<T>& jobs, int nj, hipStream_t st) {
-  static const int ns = getenv("FHVAE_CELL_BWD_NS") ? atoi(getenv("FHVAE_CELL_BWD_NS")) : 4;
-  static const int bm = getenv("FHVAE_CELL_BWD_BM") ? atoi(getenv("FHVAE_CELL_BWD_BM")) : 64;
-  static const int dbg = getenv("FHVAE_CELL_DBG") ? atoi(getenv("FHVAE_CELL_DBG")) : 0;
   BwdJobs<T> jd = jobs;
-  jd.glds = dbg;
-  const dim3 grid((unsigned)(jobs.B / (bm == 128 ? 128 : 64)), (unsigned)(jobs.H / 64), (unsigned)nj), block(kCellThreads);
-  if (bm == 128 && ns == 3)
-    hipLaunchKernelGGL((cell_bwd_kernel<T, 128, 3>), grid, block, 0, st, jd);
-  else if (bm == 128)
-    hipLaunchKernelGGL((cell_bwd_kernel<T, 128, 4>), grid, block, 0, st, jd);
-  else if (ns == 3)
-    hipLaunchKernelGGL((cell_bwd_kernel<T, 64, 3>), grid, block, 0, st, jd);
-  else
-    hipLaunchKernelGGL((cell_bwd_kernel<T, 64, 4>), grid, block, 0, st, jd);
+  jd.glds = 0;
+  const dim3 grid((unsigned)(jobs.B / 64), (unsigned)(jobs.H / 64), (unsigned)nj), block(kCellThreads);
+  hipLaunchKernelGGL((cell_bwd_kernel<T, 64, 4>), grid, block, 0, st, jd);  // (64-row tiles, four stages; 128 rows / three stages no faster)
   return fh_launch_status();
 }
 
@@ -426,10 +398,6 @@ int launch_cell_dgsum(const T* dg, float* out, int T_, int64_t n, hipStream_t st
 // explicit instantiations (the kernels' device stubs and the host entry points of both operand types)
 #define FH_CELL_INST(T)                                                    \
   template __global__ void cell_fwd_kernel<T, 2>(FwdJobs<T>);             \
-  template __global__ void cell_fwd_kernel<T, 3>(FwdJobs<T>);             \
-  template __global__ void cell_bwd_kernel<T, 128, 3>(BwdJobs<T>);        \
-  template __global__ void cell_bwd_kernel<T, 128, 4>(BwdJobs<T>);        \
-  template __global__ void cell_bwd_kernel<T, 64, 3>(BwdJobs<T>);         \
   template __global__ void cell_bwd_kernel<T, 64, 4>(BwdJobs<T>);         \
   template __global__ void cell_dgsum_kernel<T>(const T*, float*, int, int64_t); \
   template bool cell_fwd_big_ok<T>(const FwdJobs<T>&, int);               \

@@ -1342,7 +1342,7 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     p.sync = (unsigned*)d->lp;
     p.xch = w.xch;
     p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
-    p.il = getenv("FHVAE_NO_FWD_IL") ? 0 : 1;
+    p.il = 1;
     double fl = 0;
     for (int l = 0; l < L; ++l) fl += 2.0 * nrows * 4 * H * ((l > 0 ? d->T * H : 0) + (d->T - 1) * (double)H);
     const int ts = trace_begin(st, kTraceFwdCell, fl);
@@ -1383,7 +1383,7 @@ static int launch_bwd_layer(const ClBwd& p, hipStream_t st) {
   using CF = ClLayerCfg<H, RB, 32>;
   constexpr bool HW = RB <= 64 && CF::SMEM_HW <= 163840;  // helper wave where its operand buffer fits
   constexpr int SMEM = HW ? CF::SMEM_HW : CF::SMEM;
-  const bool hw = HW && !getenv("FHVAE_NO_HELPER");
+  const bool hw = HW;
   static bool attr[2] = {false, false};
   if (!attr[hw]) {
     hipError_t e = hw ? hipFuncSetAttribute((const void*)lstm_bwd_layer_kernel<H, RB, 32, HW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM)

@@ -90,7 +90,8 @@ def test_bench_shape_bf16_lstm_fwd_bwd_vs_torch_lstm(hb, I, Ic):
 
 
 @pytest.mark.parametrize("B,T,I,Ic,H,L", [(256, 6, 80, 32, 512, 2), (256, 5, 80, 0, 512, 2), (384, 4, 0, 64, 512, 2), (1024, 3, 80, 32, 512, 2),
-                                           (256, 4, 80, 32, 256, 1), (128, 4, 0, 64, 384, 2)])
+                                           (256, 4, 80, 32, 256, 1), (128, 4, 0, 64, 384, 2),
+                                           (128, 40, 80, 32, 512, 2)])  # T = 40 (configs[4]'s segment length), forced on at B = 128
 def test_big_cells_h512_bf16_vs_torch_lstm_and_generic_cells(hb, monkeypatch, B, T, I, Ic, H, L):
     """The large-tile bf16 cells for H = 512 (configs[3] at the bench batch: lstm_cell.hip, one launch per wavefront step), forced on
     at a batch the CPU oracle handles, against
@@ -119,7 +120,8 @@ def test_big_cells_h512_bf16_vs_torch_lstm_and_generic_cells(hb, monkeypatch, B,
             assert rel < 4e-3, (mode, k, rel)
 
 
-@pytest.mark.parametrize("B,T,I,Ic,H,L", [(256, 5, 80, 32, 256, 2), (128, 4, 0, 64, 256, 2), (256, 3, 80, 0, 512, 2), (128, 4, 80, 32, 256, 1)])
+@pytest.mark.parametrize("B,T,I,Ic,H,L", [(256, 5, 80, 32, 256, 2), (128, 4, 0, 64, 256, 2), (256, 3, 80, 0, 512, 2), (128, 4, 80, 32, 256, 1),
+                                           (128, 40, 80, 32, 512, 2), (128, 40, 0, 64, 512, 2)])  # what configs[4] runs, at T = 40
 def test_big_cells_f32_vs_torch_lstm(hb, monkeypatch, B, T, I, Ic, H, L):
     """The large-tile cells with f32 operands (exact-f32 MFMA; what configs[4] runs at its batch), forced on at a batch the CPU
     oracle handles: the parity-mode tolerance of the other f32 LSTM tests, 1e-4 of each tensor's max, forward and gradients."""
@@ -302,7 +304,8 @@ def test_disc_converged_regime(hb, B, S, scale, noise):
 
 
 @pytest.mark.parametrize("B,S,scale,noise", [(2048, 28000, 1.0, None), (256, 4600, 1.0, None), (512, 9000, 3.0, 0.3),
-                                             (300, 5000, 1.0, 0.05), (1024, 40000, 1.0, None)])
+                                             (300, 5000, 1.0, 0.05), (1024, 40000, 1.0, None),
+                                             (512, 100000, 1.0, None), (256, 100000, 1.0, 0.05)])  # configs[3]'s table
 def test_disc_bf16_mode_vs_direct_f64(hb, B, S, scale, noise):
     """K5 in the bf16 compute mode (hip_binding.disc_lse(..., lp=True): cross terms on bf16 MFMA with hi/lo-split operands,
     second products with bf16 weights; csrc/disc_lp.hip) against the direct form in float64.  Stated tolerance of that mode:

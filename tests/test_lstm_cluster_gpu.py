@@ -150,3 +150,59 @@ def test_partial_dh_backward_vs_dg_exchange(hb, B, T, Ic):
     if Ic:
         err = (a[3] - b[3]).abs().max().item()
         assert err <= 2e-2 * b[3].abs().max().item() + 1e-6, ("d_xc", err)
+
+
+# every FHVAE_* switch the library still reads selects an alternative kernel or schedule inside the shipped .so: each one gets a
+# parity smoke against the default path at a shape where it takes effect (B, T, I, Ic, H, L; extra environment)
+SWITCHES = [("FHVAE_NO_CLUSTER", "1", (1024, 4, 80, 32, 256, 2), {}),      # per-step cells instead of the persistent kernels
+            ("FHVAE_NO_RS", "1", (1024, 4, 80, 32, 256, 2), {}),           # dg-exchange backward + cluster forward
+            ("FHVAE_NO_FWD_WR", "1", (1024, 4, 80, 32, 256, 2), {}),       # cluster forward beside the partial-dh backward
+            ("FHVAE_NO_FOLD", "1", (1024, 4, 80, 32, 256, 2), {}),         # layer-0 input projection as a GEMM
+            ("FHVAE_NO_XC_FOLD", "1", (1024, 4, 0, 64, 256, 2), {}),       # time-constant projection as a GEMM
+            ("FHVAE_NO_WGRAD", "1", (1024, 4, 80, 32, 256, 2), {}),        # weight gradients on the generic engine
+            ("FHVAE_NO_GLDS", "1", (256, 4, 80, 32, 256, 2), {"FHVAE_NO_CLUSTER": "1"}),   # step cells staged through registers
+            ("FHVAE_NO_GROUP", "1", (256, 4, 80, 32, 256, 2), {"FHVAE_NO_CLUSTER": "1"}),  # no grouped GEMM launches
+            ("FHVAE_BIG_CELLS", "1", (256, 4, 80, 32, 512, 2), {}),        # large-tile cells forced on
+            ("FHVAE_BIG_CELLS", "0", (2048, 3, 80, 32, 512, 2), {})]       # ... and off where they are the default
+
+
+@pytest.mark.parametrize("name,value,shape,extra", SWITCHES)
+def test_switch_parity_smoke(hb, name, value, shape, extra):
+    B, T, I, Ic, H, L = shape
+    torch.manual_seed(B + T + H)
+    lstm = torch.nn.LSTM(I + Ic, H, L)
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    params = [getattr(lstm, n).detach().cuda() for n in names]
+    x = torch.randn(T, B, I).cuda() if I else None
+    xc = torch.randn(B, Ic).cuda() if Ic else None
+    g_out, g_hn = torch.randn(T, B, H).cuda(), torch.randn(B, L * H).cuda()
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ps = [p.detach().clone().requires_grad_(True) for p in params]
+            xcd = xc.detach().clone().requires_grad_(True) if xc is not None else None
+            hs_top, hn = hb.lstm_seq(x, xcd, T, ps, hb.BF16)
+            ((hs_top * g_out).sum() + (hn * g_hn).sum()).backward()
+            hb.flush_param_grads()
+            torch.cuda.synchronize()
+            return hs_top.detach(), hn.detach(), [p.grad for p in ps], (xcd.grad if xcd is not None else None)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    a = run(dict(extra))
+    b = run(dict(extra, **{name: value}))
+    assert hb.lstm_sync_status() == 0
+    for u, v in ((a[0], b[0]), (a[1], b[1])):
+        d = (u - v).abs()
+        assert torch.isfinite(v).all() and d.max().item() < 2e-2 and d.mean().item() < 5e-4, (name, d.max().item(), d.mean().item())
+    for n, gu, gv in zip(names, a[2], b[2]):
+        scale = gu.abs().max().item() + 1e-30
+        assert (gu - gv).abs().max().item() < 2e-2 * scale, (name, n, (gu - gv).abs().max().item(), scale)
+    if Ic:
+        assert (a[3] - b[3]).abs().max().item() < 2e-2 * (a[3].abs().max().item() + 1e-30), (name, "d_xc")
