@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 7
+#define FHVAE_ABI_VERSION 8
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -81,6 +81,28 @@ int fhvae_gauss_head_reparam_fwd(const void* h, int64_t ldh, const void* w_mu, c
  * stride ldo): mu in columns [0,D), logvar in [D,2D). */
 int fhvae_gauss_head_pair_fwd(const void* h_lp, int64_t ldh, const void* w_pair_lp, const float* b_mu, const float* b_lv,
                               float* out, int64_t ldo, int64_t M, int64_t K, int64_t D, void* stream);
+/* The stacked bf16 operands of a Gaussian head from its f32 master weights w_mu, w_lv [D,K] (nn.Linear layout,
+ * simple_fhvae.py:197-198), one launch: wl_pair [2D,K] (forward: fhvae_gauss_head_pair_fwd) and wt_pair [K,ldt] =
+ * [w_mu^T | w_lv^T | 0] (backward: fhvae_gauss_head_bwd_pair), ldt >= 2D. */
+int fhvae_head_pair_weights(const float* w_mu, const float* w_lv, void* wl_pair, void* wt_pair, int64_t ldt,
+                            int64_t D, int64_t K, void* stream);
+/* sample[m,c] = out[m,c] + eps[m,c] * exp(0.5 * out[m,D+c]) on the side-by-side (mu | logvar) buffer of
+ * fhvae_gauss_head_pair_fwd (simple_fhvae.py:214-216); mu / logvar (may be NULL): contiguous [M,D] copies of the two halves. */
+int fhvae_gauss_reparam_pair_fwd(const float* out, int64_t ldo, const float* eps, float* sample, float* mu, float* logvar,
+                                 int64_t M, int64_t D, void* stream);
+/* g_lp[m, 0..D) = bf16(d_mu + d_sample), [D..2D) = bf16(d_logvar + d_sample * eps * 0.5 * exp(0.5 logvar)), [2D..ldg) = 0:
+ * the upstream gradient of both linear layers of a head as one bf16 operand (any of d_mu / d_logvar / d_sample may be NULL;
+ * d_sample needs eps and logvar; logvar has row stride ld_lv). */
+int fhvae_gauss_reparam_bwd_pair(const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
+                                 const float* logvar, int64_t ld_lv, void* g_lp, int64_t ldg, int64_t M, int64_t D,
+                                 void* stream);
+/* Backward of both linear layers of a head (nn.Linear backward at simple_fhvae.py:197-198,:210-211) from the bf16 operand
+ * g_lp [M,ldg] (fhvae_gauss_reparam_bwd_pair or fhvae_elbo_bwd's d_x_pair_lp): dh[M,K] = g . [W_mu; W_lv] (OVERWRITTEN, may be
+ * NULL), dw_mu / dw_lv [D,K] += g^T . h_lp (skipped when both are NULL), db_mu / db_lv [D] += column sums of g (the sum of the
+ * col_sum_rows partial rows col_sum[.][2D] when given, else reduced here).  wt_pair [K,ldt] from fhvae_head_pair_weights. */
+int fhvae_gauss_head_bwd_pair(const void* h_lp, int64_t ldh, const void* wt_pair, int64_t ldt, const void* g_lp, int64_t ldg,
+                              const float* col_sum, int64_t col_sum_rows, float* dh, int64_t lddh, float* dw_mu, float* dw_lv, float* db_mu,
+                              float* db_lv, int64_t M, int64_t K, int64_t D, void* stream);
 
 /* Elementwise part of the head's backward: given upstream d_mu, d_logvar, d_sample (any may be
  * NULL = zero) produce the gradients w.r.t. the two linear outputs:
@@ -98,15 +120,6 @@ int fhvae_gauss_head_bwd(const float* h, int64_t ldh, const float* w_mu, const f
                          const float* eps, const float* logvar, float* g_ws, float* dh, int64_t lddh,
                          float* dw_mu, float* dw_lv, float* db_mu, float* db_lv, int64_t M, int64_t K,
                          int64_t D, void* stream);
-/* The same with bf16 MFMA operands (compute_dtype = bf16): h_lp [M,K] bf16, w_mu_t_lp / w_lv_t_lp [K,D] bf16 = the
- * TRANSPOSED weights (fhvae_cast_bf16's dst_t), g_lp [M,2D] bf16 workspace.  Accumulation, dh and the parameter
- * gradients stay f32. */
-int fhvae_gauss_head_bwd_lp(const void* h_lp, int64_t ldh, const void* w_mu_t_lp, const void* w_lv_t_lp,
-                            const float* d_mu, const float* d_logvar, const float* d_sample,
-                            const float* eps, const float* logvar, void* g_lp, float* dh, int64_t lddh,
-                            float* dw_mu, float* dw_lv, float* db_mu, float* db_lv, int64_t M, int64_t K,
-                            int64_t D, void* stream);
-
 /* ------------------------------------------------------------------------------------------
  * Multi-layer LSTM over a whole segment (K1), step-fused cells: one launch per wavefront step
  * computes the 4-gate contraction on MFMA and applies sigmoid/tanh + the cell update in the
@@ -204,7 +217,18 @@ int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* d, void* stream);
  * gradients of several nets.  In BF16 mode the long contractions dW[4H,.] += dgates^T . [x | h] over the T*B rows of ALL the
  * descriptors run as ONE grouped launch (csrc/wgrad.hip); the host defers them to the end of the backward pass, where the
  * three nets of the model together fill the chip with whole tiles and few K slices. */
-int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* descs, int n, void* stream);
+/* `extra` (may be NULL with n_extra = 0): further contractions C[M,N] += A[K,M]^T . B[K,N] of the same kind (the heads' weight
+ * gradients) that ride in the same grouped launch; each must satisfy fhvae_wgrad_desc_ok. */
+typedef struct fhvae_wgrad_desc {
+  const void* a; int64_t lda;  /* [K, lda] bf16: the contraction index is the ROW */
+  int64_t a_col0;              /* `a` points a_col0 columns into the rows of its buffer (a column slice) */
+  const void* b; int64_t ldb;  /* [K, ldb] bf16 */
+  float* c; int64_t ldc;       /* [M, ldc] f32, accumulated */
+  int64_t M, N, K;
+} fhvae_wgrad_desc;
+int fhvae_wgrad_desc_ok(const fhvae_wgrad_desc* p); /* 1 = the grouped kernel takes it (alignment, ranges), else 0 */
+int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* descs, int n, const fhvae_wgrad_desc* extra, int n_extra,
+                                 void* stream);
 /* The contraction itself: C[M,N] (f32, ldc) += A[K,M]^T . B[K,N], bf16 operands whose ROW index is the contraction index
  * (lda, ldb in elements, multiples of 8; 16-byte aligned bases; K*ld*2 < 2^30) -- dW += dY^T X of a linear / LSTM layer over
  * K = batch x time rows (autograd of nn.Linear, simple_fhvae.py:127-134; of the LSTM body missing at fhvae.py:14).
@@ -268,9 +292,16 @@ typedef struct fhvae_elbo_bwd_desc {
   /* outputs, OVERWRITTEN; same layouts as the forward inputs; d_x_mu/d_x_lv may be NULL */
   float* d_x_mu; float* d_x_lv;
   float* d_z1_mu; float* d_z1_lv; float* d_z2_mu; float* d_z2_lv; float* d_mu2;
+  /* optional (NULL = off; needs d_x_mu / d_x_lv, F % 4 == 0, F <= 256, 16-byte aligned buffers and time-major rows
+     r = t*B + b): the decoder-output gradients once more as ONE bf16 matrix, the operand of the per-frame head's backward
+     contractions (fhvae_gauss_head_bwd_pair): d_x_pair_lp[r*ld_pair + 0..F) = d_x_mu, [F..2F) = d_x_lv, [2F..ld_pair) = 0,
+     and partial column sums of them, d_x_colsum[fhvae_elbo_colsum_rows(B)][2F] (OVERWRITTEN; the sum over its rows = the
+     head's bias gradients) */
+  void* d_x_pair_lp; int64_t ld_pair; float* d_x_colsum;
 } fhvae_elbo_bwd_desc;
 
 int fhvae_elbo_bwd(const fhvae_elbo_bwd_desc* d, void* stream);
+int64_t fhvae_elbo_colsum_rows(int64_t B);
 
 /* ------------------------------------------------------------------------------------------
  * Discriminative loss (K5): logits[b,s] = -sum_d (q[b,d]-table[s,d])^2 * inv_two_var,

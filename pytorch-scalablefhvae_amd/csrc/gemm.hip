@@ -4,7 +4,9 @@
 // simple_fhvae.py:193-216.
 #include "gemm_launch.h"
 #include "proj.h"
+#include "wgrad.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace fh {
@@ -530,6 +532,88 @@ __global__ void reparam_bwd_cat_kernel(const float* __restrict__ d_mu, const flo
   }
 }
 
+// the stacked bf16 operands of a Gaussian head: wl [2D,K] and wt [K,ldt] = [w_mu^T | w_lv^T | 0]
+__global__ void head_pair_weights_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_lv, u16* __restrict__ wl,
+                                         u16* __restrict__ wt, int64_t ldt, int D, int K) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ldt * K) return;
+  const int r = (int)(i / K), k = (int)(i - (int64_t)r * K);  // r: stacked output row (consecutive threads walk k: coalesced reads)
+  u16 v = 0;
+  if (r < 2 * D) {
+    v = f2bf(r < D ? w_mu[(int64_t)r * K + k] : w_lv[(int64_t)(r - D) * K + k]);
+    if (wl) wl[(int64_t)r * K + k] = v;
+  }
+  if (wt) wt[(int64_t)k * ldt + r] = v;
+}
+
+__global__ void reparam_pair_fwd_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ eps,
+                                        float* __restrict__ smp, float* __restrict__ mu_c, float* __restrict__ lv_c, int64_t n, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t m = i / D, c = i - m * D;
+  const float mu = out[m * ldo + c], lv = out[m * ldo + D + c];
+  smp[i] = mu + eps[i] * expf(0.5f * lv);  // simple_fhvae.py:214-216
+  if (mu_c) mu_c[i] = mu;
+  if (lv_c) lv_c[i] = lv;
+}
+
+// thread = 8 consecutive columns of a row of g (one 16-byte store); columns [2D, ldg) are zero
+__global__ void reparam_bwd_pair_kernel(const float* __restrict__ d_mu, const float* __restrict__ d_lv, const float* __restrict__ d_s,
+                                        const float* __restrict__ eps, const float* __restrict__ lv, int64_t ld_lv,
+                                        u16* __restrict__ g, int64_t ldg, int64_t M, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = (int)(ldg / 8);
+  if (i >= M * per) return;
+  const int64_t m = i / per;
+  const int c0 = (int)(i - m * per) * 8;
+  union {
+    u16 h[8];
+    uint4 v;
+  } o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c0 + k;
+    float v = 0.f;
+    if (c < D) {
+      v = (d_mu ? d_mu[m * D + c] : 0.f) + (d_s ? d_s[m * D + c] : 0.f);
+    } else if (c < 2 * D) {
+      const int64_t j = m * D + (c - D);
+      v = (d_lv ? d_lv[j] : 0.f) + ((d_s && eps) ? d_s[j] * eps[j] * 0.5f * expf(0.5f * lv[m * ld_lv + (c - D)]) : 0.f);
+    }
+    o.h[k] = f2bf(v);
+  }
+  *(uint4*)(g + m * ldg + c0) = o.v;
+}
+
+// a[0..D) += column sums of src[rows][2D] (columns [0, D)), b likewise (columns [D, 2D)).  grid = (64-column groups, row
+// chunks): wave w of chunk y takes rows (4y + w) + 4 gridDim.y k, eight independent loads in flight; one atomic per column and
+// workgroup.
+__global__ __launch_bounds__(256) void add_split_kernel(const float* __restrict__ src, int rows, float* __restrict__ a,
+                                                        float* __restrict__ b, int D) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const int step = 4 * gridDim.y;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < 2 * D) {
+    for (int r = blockIdx.y * 4 + wave; r < rows; r += 8 * step) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (r + k * step < rows) acc[k] += src[(int64_t)(r + k * step) * 2 * D + i];
+    }
+  }
+  part[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (wave == 0 && i < 2 * D) {
+    const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (i < D) {
+      if (a) atomicAdd(a + i, v);
+    } else if (b) {
+      atomicAdd(b + (i - D), v);
+    }
+  }
+}
+
 }  // namespace fh
 
 using namespace fh;
@@ -685,6 +769,117 @@ extern "C" int fhvae_gauss_head_pair_fwd(const void* h_lp, int64_t ldh, const vo
   return launch_gemm_group(ps, 2, FHVAE_BF16, st);
 }
 
+extern "C" int fhvae_head_pair_weights(const float* w_mu, const float* w_lv, void* wl_pair, void* wt_pair, int64_t ldt, int64_t D,
+                                       int64_t K, void* stream) {
+  FH_CHECK_PTR(w_mu);
+  FH_CHECK_PTR(w_lv);
+  if (!wl_pair && !wt_pair) return FHVAE_ERR_NULL;
+  FH_CHECK_POS(D);
+  FH_CHECK_POS(K);
+  if (ldt < 2 * D) return FHVAE_ERR_SHAPE;
+  hipLaunchKernelGGL(head_pair_weights_kernel, dim3((unsigned)fh_cdiv(ldt * K, 256)), dim3(256), 0, (hipStream_t)stream, w_mu, w_lv,
+                     (u16*)wl_pair, (u16*)wt_pair, ldt, (int)D, (int)K);
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_gauss_reparam_pair_fwd(const float* out, int64_t ldo, const float* eps, float* sample, float* mu, float* logvar,
+                                            int64_t M, int64_t D, void* stream) {
+  FH_CHECK_PTR(out);
+  FH_CHECK_PTR(eps);
+  FH_CHECK_PTR(sample);
+  FH_CHECK_POS(M);
+  FH_CHECK_POS(D);
+  if (ldo < 2 * D) return FHVAE_ERR_SHAPE;
+  hipLaunchKernelGGL(reparam_pair_fwd_kernel, dim3((unsigned)fh_cdiv(M * D, 256)), dim3(256), 0, (hipStream_t)stream, out, ldo, eps,
+                     sample, mu, logvar, M * D, (int)D);
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_gauss_reparam_bwd_pair(const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
+                                            const float* logvar, int64_t ld_lv, void* g_lp, int64_t ldg, int64_t M, int64_t D,
+                                            void* stream) {
+  FH_CHECK_PTR(g_lp);
+  FH_CHECK_POS(M);
+  FH_CHECK_POS(D);
+  if (d_sample && (!eps || !logvar)) return FHVAE_ERR_NULL;
+  if (ldg < 2 * D || ldg % 8) return FHVAE_ERR_SHAPE;
+  if (((uintptr_t)g_lp) & 15) return FHVAE_ERR_ALIGN;
+  hipLaunchKernelGGL(reparam_bwd_pair_kernel, dim3((unsigned)fh_cdiv(M * (ldg / 8), 256)), dim3(256), 0, (hipStream_t)stream, d_mu,
+                     d_logvar, d_sample, eps, logvar, ld_lv, (u16*)g_lp, ldg, M, (int)D);
+  return fh_launch_status();
+}
+
+extern "C" int fhvae_gauss_head_bwd_pair(const void* h_lp, int64_t ldh, const void* wt_pair, int64_t ldt, const void* g_lp, int64_t ldg,
+                                         const float* col_sum, int64_t col_sum_rows, float* dh, int64_t lddh, float* dw_mu, float* dw_lv, float* db_mu,
+                                         float* db_lv, int64_t M, int64_t K, int64_t D, void* stream) {
+  FH_CHECK_PTR(g_lp);
+  FH_CHECK_POS(M);
+  FH_CHECK_POS(K);
+  FH_CHECK_POS(D);
+  FH_CHECK_I32(M);
+  FH_CHECK_I32(K);
+  FH_CHECK_I32(2 * D);
+  if (ldg < 2 * D || ldt < 2 * D) return FHVAE_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const u16* g = (const u16*)g_lp;
+  int e;
+  if (dh) {  // dh[M,K] = g[M, 0..ldg) . wt_pair[K, 0..ldg)^T (the zero padding of both contributes nothing)
+    FH_CHECK_PTR(wt_pair);
+    if (ldt == ldg && proj_eligible(g, ldg, wt_pair, ldt, dh, lddh, M, K, ldg)) {
+      e = launch_proj(g, ldg, wt_pair, ldt, dh, lddh, nullptr, M, K, ldg, st);
+    } else {
+      GemmParams p = {};
+      p.seg[0] = Seg{g, ldg, 1, wt_pair, ldt, 1, (int)(2 * D)};
+      p.M = (int)M;
+      p.N = (int)K;
+      p.C = dh;
+      p.ldc = lddh;
+      p.splitk = 1;
+      e = launch_gemm(p, FHVAE_BF16, st);
+    }
+    if (e) return e;
+  }
+  if (dw_mu || dw_lv) {
+    FH_CHECK_PTR(h_lp);
+    FH_CHECK_PTR(dw_mu);
+    FH_CHECK_PTR(dw_lv);
+    WgProblem wp[2] = {};
+    for (int i = 0; i < 2; ++i) {
+      wp[i].A = g + i * D, wp[i].B = (const u16*)h_lp, wp[i].C = i == 0 ? dw_mu : dw_lv;
+      wp[i].lda = ldg, wp[i].ldb = ldh, wp[i].ldc = K;
+      wp[i].M = (int)D, wp[i].N = (int)K, wp[i].K = (int)M;
+      wp[i].a_col0 = (int)(i * D);
+    }
+    if (wgrad_eligible(wp[0]) && wgrad_eligible(wp[1])) {
+      e = launch_wgrad(wp, 2, st);
+    } else {
+      GemmParams p = {};
+      p.seg[0] = Seg{g, ldg, 0, h_lp, ldh, 0, (int)M};
+      p.M = (int)(2 * D);
+      p.N = (int)K;
+      p.C = dw_mu;
+      p.C2 = dw_lv;
+      p.c_split = (int)D;
+      p.ldc = K;
+      p.mode = 1;
+      p.splitk = 0;
+      e = launch_gemm(p, FHVAE_BF16, st);
+    }
+    if (e) return e;
+  }
+  if (db_mu || db_lv) {
+    if (col_sum) {
+      if (col_sum_rows <= 0 || col_sum_rows > INT32_MAX) return FHVAE_ERR_SHAPE;
+      const unsigned gy = (unsigned)std::min<int64_t>(32, fh_cdiv(col_sum_rows, 32));
+      hipLaunchKernelGGL(add_split_kernel, dim3((unsigned)fh_cdiv(2 * D, 64), gy), dim3(256), 0, st, col_sum, (int)col_sum_rows, db_mu,
+                         db_lv, (int)D);
+      return fh_launch_status();
+    }
+    return launch_colsum(g, FHVAE_BF16, ldg, db_mu, db_lv, M, 2 * D, st, D);
+  }
+  return FHVAE_OK;
+}
+
 extern "C" int fhvae_gauss_reparam_bwd(const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
                                        const float* logvar, float* g_mu, float* g_lv, int64_t n, void* stream) {
   FH_CHECK_PTR(g_mu);
@@ -749,58 +944,3 @@ extern "C" int fhvae_gauss_head_bwd(const float* h, int64_t ldh, const float* w_
   return FHVAE_OK;
 }
 
-// bf16-operand form of the above (compute_dtype = bf16): h_lp [M,K] bf16 (the LSTM's own hidden-state buffer), the transposed
-// bf16 weights w_*_t_lp [K,D] (fhvae_cast_bf16), g_lp [M,2D] bf16 workspace; accumulation, dh and the parameter gradients f32
-extern "C" int fhvae_gauss_head_bwd_lp(const void* h_lp, int64_t ldh, const void* w_mu_t_lp, const void* w_lv_t_lp,
-                                       const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
-                                       const float* logvar, void* g_lp, float* dh, int64_t lddh, float* dw_mu, float* dw_lv,
-                                       float* db_mu, float* db_lv, int64_t M, int64_t K, int64_t D, void* stream) {
-  FH_CHECK_PTR(g_lp);
-  FH_CHECK_POS(M);
-  FH_CHECK_POS(K);
-  FH_CHECK_POS(D);
-  FH_CHECK_I32(M);
-  FH_CHECK_I32(K);
-  FH_CHECK_I32(2 * D);
-  if (d_sample && (!eps || !logvar)) return FHVAE_ERR_NULL;
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t n = M * D;
-  u16* g = (u16*)g_lp;
-  hipLaunchKernelGGL(reparam_bwd_cat_kernel<u16>, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, d_mu, d_logvar, d_sample, eps,
-                     logvar, g, n, (int)D);
-  int e = fh_launch_status();
-  if (e) return e;
-  if (dh) {  // dh[M,K] = g_mu . W_mu + g_lv . W_lv with the transposed weight copies as KC operands
-    FH_CHECK_PTR(w_mu_t_lp);
-    FH_CHECK_PTR(w_lv_t_lp);
-    GemmParams p = {};
-    p.seg[0] = Seg{g, 2 * D, 1, w_mu_t_lp, D, 1, (int)D};
-    p.seg[1] = Seg{g + D, 2 * D, 1, w_lv_t_lp, D, 1, (int)D};
-    p.M = (int)M;
-    p.N = (int)K;
-    p.C = dh;
-    p.ldc = lddh;
-    p.splitk = 1;
-    e = launch_gemm(p, FHVAE_BF16, st);
-    if (e) return e;
-  }
-  if (dw_mu || dw_lv) {
-    FH_CHECK_PTR(h_lp);
-    FH_CHECK_PTR(dw_mu);
-    FH_CHECK_PTR(dw_lv);
-    GemmParams p = {};
-    p.seg[0] = Seg{g, 2 * D, 0, h_lp, ldh, 0, (int)M};
-    p.M = (int)(2 * D);
-    p.N = (int)K;
-    p.C = dw_mu;
-    p.C2 = dw_lv;
-    p.c_split = (int)D;
-    p.ldc = K;
-    p.mode = 1;
-    p.splitk = 0;
-    e = launch_gemm(p, FHVAE_BF16, st);
-    if (e) return e;
-  }
-  if (db_mu || db_lv) return launch_colsum(g, FHVAE_BF16, 2 * D, db_mu, db_lv, M, 2 * D, st, D);
-  return FHVAE_OK;
-}

@@ -130,17 +130,59 @@ __global__ __launch_bounds__(256) void elbo_fwd_kernel(fhvae_elbo_desc d) {
   }
 }
 
+__device__ __forceinline__ void elbo_dx4(const float4& a, const float4& mu, const float4& lv, float gpx, float4& gm, float4& gl) {
+  const float av[4] = {a.x, a.y, a.z, a.w}, mv[4] = {mu.x, mu.y, mu.z, mu.w}, lvv[4] = {lv.x, lv.y, lv.z, lv.w};
+  float m[4], l[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float df = av[k] - mv[k], iv = 1.f / expf(lvv[k]);
+    m[k] = gpx * df * iv;
+    l[k] = gpx * -0.5f * (1.f - df * df * iv);
+  }
+  gm = make_float4(m[0], m[1], m[2], m[3]);
+  gl = make_float4(l[0], l[1], l[2], l[3]);
+}
+
+struct ElboG {
+  float gpx, gk1, gk2, gpm;
+};
+__device__ __forceinline__ ElboG elbo_upstream(const fhvae_elbo_bwd_desc& bd, int64_t b) {
+  const fhvae_elbo_desc& d = bd.f;
+  const float glb = bd.g_lower_bound ? bd.g_lower_bound[b] : 0.f;
+  ElboG g;
+  g.gpx = glb + (bd.g_log_px_z ? bd.g_log_px_z[b] : 0.f);
+  g.gk1 = glb + (bd.g_neg_kld_z1 ? bd.g_neg_kld_z1[b] : 0.f);
+  g.gk2 = glb + (bd.g_neg_kld_z2 ? bd.g_neg_kld_z2[b] : 0.f);
+  const float ns = d.num_segs ? (float)d.num_segs[b] : (float)d.nsegs_scalar;
+  g.gpm = glb / ns + (bd.g_log_pmu2 ? bd.g_log_pmu2[b] : 0.f);
+  return g;
+}
+// the latent terms' gradients of segment b (one wave)
+__device__ __forceinline__ void elbo_dz(const fhvae_elbo_bwd_desc& bd, int64_t b, int lane, const ElboG& g) {
+  const fhvae_elbo_desc& d = bd.f;
+  const float v2 = expf(kPz2Logvar);
+  for (int j = lane; j < d.D1; j += 64) {
+    const int64_t o = b * d.D1 + j;
+    const float mu = d.z1_mu[o], lv = d.z1_lv[o];
+    bd.d_z1_mu[o] = -mu * g.gk1;
+    bd.d_z1_lv[o] = 0.5f * (1.f - expf(lv)) * g.gk1;
+  }
+  for (int j = lane; j < d.D2; j += 64) {
+    const int64_t o = b * d.D2 + j;
+    const float mu = d.z2_mu[o], lv = d.z2_lv[o], m2 = d.mu2[o];
+    const float df = (mu - m2) / v2;
+    bd.d_z2_mu[o] = -df * g.gk2;
+    bd.d_z2_lv[o] = 0.5f * (1.f - expf(lv) / v2) * g.gk2;
+    bd.d_mu2[o] = df * g.gk2 + (bd.reference_detach ? 0.f : -m2 * g.gpm);
+  }
+}
+
 __global__ __launch_bounds__(256) void elbo_bwd_kernel(fhvae_elbo_bwd_desc bd) {
   const fhvae_elbo_desc& d = bd.f;
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= d.B) return;
-  const float glb = bd.g_lower_bound ? bd.g_lower_bound[b] : 0.f;
-  const float gpx = glb + (bd.g_log_px_z ? bd.g_log_px_z[b] : 0.f);
-  const float gk1 = glb + (bd.g_neg_kld_z1 ? bd.g_neg_kld_z1[b] : 0.f);
-  const float gk2 = glb + (bd.g_neg_kld_z2 ? bd.g_neg_kld_z2[b] : 0.f);
-  const float ns = d.num_segs ? (float)d.num_segs[b] : (float)d.nsegs_scalar;
-  const float gpm = glb / ns + (bd.g_log_pmu2 ? bd.g_log_pmu2[b] : 0.f);
+  const ElboG g = elbo_upstream(bd, b);
   if (bd.d_x_mu && bd.d_x_lv && !bd.reference_detach) {
     const float* x = d.x + b * d.x_sb;
     const float* xm = d.x_mu + b * d.xo_sb;
@@ -154,30 +196,8 @@ __global__ __launch_bounds__(256) void elbo_bwd_kernel(fhvae_elbo_bwd_desc bd) {
       for (int i = lane; i < n4; i += 64) {
         const int t = i / F4, f = (i % F4) * 4;
         const int64_t o = t * d.xo_st + f;
-        const float4 a = *(const float4*)(x + t * d.x_st + f);
-        const float4 mu = *(const float4*)(xm + o);
-        const float4 lv = *(const float4*)(xl + o);
         float4 gm, gl;
-        {
-          const float df = a.x - mu.x, iv = 1.f / expf(lv.x);
-          gm.x = gpx * df * iv;
-          gl.x = gpx * -0.5f * (1.f - df * df * iv);
-        }
-        {
-          const float df = a.y - mu.y, iv = 1.f / expf(lv.y);
-          gm.y = gpx * df * iv;
-          gl.y = gpx * -0.5f * (1.f - df * df * iv);
-        }
-        {
-          const float df = a.z - mu.z, iv = 1.f / expf(lv.z);
-          gm.z = gpx * df * iv;
-          gl.z = gpx * -0.5f * (1.f - df * df * iv);
-        }
-        {
-          const float df = a.w - mu.w, iv = 1.f / expf(lv.w);
-          gm.w = gpx * df * iv;
-          gl.w = gpx * -0.5f * (1.f - df * df * iv);
-        }
+        elbo_dx4(*(const float4*)(x + t * d.x_st + f), *(const float4*)(xm + o), *(const float4*)(xl + o), g.gpx, gm, gl);
         *(float4*)(dm + o) = gm;
         *(float4*)(dl + o) = gl;
       }
@@ -188,26 +208,85 @@ __global__ __launch_bounds__(256) void elbo_bwd_kernel(fhvae_elbo_bwd_desc bd) {
         const int64_t o = t * d.xo_st + f;
         const float df = x[t * d.x_st + f] - xm[o];
         const float iv = 1.f / expf(xl[o]);
-        dm[o] = gpx * df * iv;
-        dl[o] = gpx * -0.5f * (1.f - df * df * iv);
+        dm[o] = g.gpx * df * iv;
+        dl[o] = g.gpx * -0.5f * (1.f - df * df * iv);
       }
     }
   }
-  const float v2 = expf(kPz2Logvar);
-  for (int j = lane; j < d.D1; j += 64) {
-    const int64_t o = b * d.D1 + j;
-    const float mu = d.z1_mu[o], lv = d.z1_lv[o];
-    bd.d_z1_mu[o] = -mu * gk1;
-    bd.d_z1_lv[o] = 0.5f * (1.f - expf(lv)) * gk1;
+  elbo_dz(bd, b, lane, g);
+}
+
+// The same with the bf16 pair copy of [d_x_mu | d_x_lv] and its column sums (fhvae_elbo_bwd_desc::d_x_pair_lp).  Two waves per
+// segment, two segments per workgroup (twice the waves of the kernel above: the passes of a wave are latency-bound); lanes ->
+// (row of the pass, 4 columns), so every lane keeps ONE column group over all its rows and the column sums stay in registers
+// (F = 80: 3 rows x 20 groups per pass, 4 lanes idle); a wave's passes are loaded four at a time before any is used.
+// Column sums: one partial row per workgroup (no atomics; fhvae_gauss_head_bwd_pair reduces the rows).
+__global__ __launch_bounds__(256) void elbo_bwd_pair_kernel(fhvae_elbo_bwd_desc bd) {
+  const fhvae_elbo_desc& d = bd.f;
+  __shared__ float cs[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 2 + (wave >> 1);
+  const int half = wave & 1;
+  const int F = (int)d.F, F4 = F / 4, RP = 64 / F4, T = (int)d.T;
+  const int rsub = lane / F4, f = (lane % F4) * 4;
+  const bool act = lane < RP * F4 && b < d.B;
+  float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sl = sm;
+  if (b < d.B) {
+    const ElboG g = elbo_upstream(bd, b);
+    const float* x = d.x + b * d.x_sb;
+    const float* xm = d.x_mu + b * d.xo_sb;
+    const float* xl = d.x_lv + b * d.xo_sb;
+    float* dm = bd.d_x_mu + b * d.xo_sb;
+    float* dl = bd.d_x_lv + b * d.xo_sb;
+    u16* gp = (u16*)bd.d_x_pair_lp;
+    const int npass = (T + RP - 1) / RP;
+    for (int p0 = half; p0 < npass; p0 += 8) {  // this wave's passes p0, p0 + 2, p0 + 4, p0 + 6
+      float4 a[4], mu[4], lv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = (p0 + 2 * k) * RP + rsub;
+        if (act && t < T) {
+          const int64_t o = t * d.xo_st + f;
+          a[k] = *(const float4*)(x + t * d.x_st + f);
+          mu[k] = *(const float4*)(xm + o);
+          lv[k] = *(const float4*)(xl + o);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = (p0 + 2 * k) * RP + rsub;
+        if (act && t < T) {
+          const int64_t o = t * d.xo_st + f;
+          float4 gm, gl;
+          elbo_dx4(a[k], mu[k], lv[k], g.gpx, gm, gl);
+          *(float4*)(dm + o) = gm;
+          *(float4*)(dl + o) = gl;
+          u16* row = gp + ((int64_t)t * d.B + b) * bd.ld_pair;
+          *(uint2*)(row + f) = uint2{(uint32_t)f2bf(gm.x) | ((uint32_t)f2bf(gm.y) << 16), (uint32_t)f2bf(gm.z) | ((uint32_t)f2bf(gm.w) << 16)};
+          *(uint2*)(row + F + f) = uint2{(uint32_t)f2bf(gl.x) | ((uint32_t)f2bf(gl.y) << 16), (uint32_t)f2bf(gl.z) | ((uint32_t)f2bf(gl.w) << 16)};
+          sm.x += gm.x, sm.y += gm.y, sm.z += gm.z, sm.w += gm.w;
+          sl.x += gl.x, sl.y += gl.y, sl.z += gl.z, sl.w += gl.w;
+        }
+      }
+    }
+    const int padc = (int)(bd.ld_pair - 2 * F) / 8;  // the zero padding of each row, in 16-byte pieces
+    for (int i = lane + 64 * half; i < T * padc; i += 128) {
+      const int t = i / padc, c = i % padc;
+      *(uint4*)(gp + ((int64_t)t * d.B + b) * bd.ld_pair + 2 * F + c * 8) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (half == 0) elbo_dz(bd, b, lane, g);
   }
-  for (int j = lane; j < d.D2; j += 64) {
-    const int64_t o = b * d.D2 + j;
-    const float mu = d.z2_mu[o], lv = d.z2_lv[o], m2 = d.mu2[o];
-    const float df = (mu - m2) / v2;
-    bd.d_z2_mu[o] = -df * gk2;
-    bd.d_z2_lv[o] = 0.5f * (1.f - expf(lv) / v2) * gk2;
-    bd.d_mu2[o] = df * gk2 + (bd.reference_detach ? 0.f : -m2 * gpm);
+  // column sums: lanes of one column group across the RP row slots (shuffles stay inside the wave), then the 4 waves through LDS
+  for (int j = lane; j < 2 * F; j += 64) cs[wave][j] = 0.f;
+  __syncthreads();
+  if (lane < RP * F4) {
+    atomicAdd(&cs[wave][f + 0], sm.x), atomicAdd(&cs[wave][f + 1], sm.y), atomicAdd(&cs[wave][f + 2], sm.z), atomicAdd(&cs[wave][f + 3], sm.w);
+    atomicAdd(&cs[wave][F + f + 0], sl.x), atomicAdd(&cs[wave][F + f + 1], sl.y), atomicAdd(&cs[wave][F + f + 2], sl.z),
+        atomicAdd(&cs[wave][F + f + 3], sl.w);
   }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * F; j += 256)
+    bd.d_x_colsum[(int64_t)blockIdx.x * 2 * F + j] = (cs[0][j] + cs[1][j]) + (cs[2][j] + cs[3][j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -721,12 +800,26 @@ extern "C" int fhvae_elbo_bwd(const fhvae_elbo_bwd_desc* d, void* stream) {
   FH_CHECK_PTR(d->d_z2_lv);
   FH_CHECK_PTR(d->d_mu2);
   if (!d->reference_detach && (!d->d_x_mu || !d->d_x_lv)) return FHVAE_ERR_NULL;
-  hipLaunchKernelGGL(elbo_bwd_kernel, dim3((unsigned)fh_cdiv(d->f.B, 4)), dim3(256), 0, (hipStream_t)stream, *d);
+  if (d->d_x_pair_lp) {  // the bf16 pair copy + column sums: vector layout with time-major rows only
+    const fhvae_elbo_desc& f = d->f;
+    FH_CHECK_PTR(d->d_x_colsum);
+    if (d->reference_detach || !d->d_x_mu) return FHVAE_ERR_NULL;
+    if (f.F % 4 || f.F > 256 || d->ld_pair < 2 * f.F || (d->ld_pair - 2 * f.F) % 8 || d->ld_pair % 8) return FHVAE_ERR_SHAPE;
+    if ((f.x_sb % 4) || (f.x_st % 4) || (f.xo_sb % 4) || (f.xo_st % 4)) return FHVAE_ERR_ALIGN;
+    if ((((uintptr_t)f.x | (uintptr_t)f.x_mu | (uintptr_t)f.x_lv | (uintptr_t)d->d_x_mu | (uintptr_t)d->d_x_lv | (uintptr_t)d->d_x_pair_lp) & 15))
+      return FHVAE_ERR_ALIGN;
+  }
+  if (d->d_x_pair_lp)
+    hipLaunchKernelGGL(elbo_bwd_pair_kernel, dim3((unsigned)fh_cdiv(d->f.B, 2)), dim3(256), 0, (hipStream_t)stream, *d);
+  else
+    hipLaunchKernelGGL(elbo_bwd_kernel, dim3((unsigned)fh_cdiv(d->f.B, 4)), dim3(256), 0, (hipStream_t)stream, *d);
   return fh_launch_status();
 }
 
 // disc_mfma.hip / disc_lp.hip: the matrix-core forms for large (B x S), D == 32 (declared in disc_mfma.h)
   // namespace fh
+
+extern "C" int64_t fhvae_elbo_colsum_rows(int64_t B) { return B > 0 ? fh_cdiv(B, 2) : 0; }
 
 extern "C" int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S) {
   if (B <= 0 || S <= 0) return 0;

@@ -950,11 +950,35 @@ extern "C" int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* bd, void* stream) {
 // Phase 2 (parameter gradients) of n backward passes whose recurrences (phase 1) have run: the long weight-gradient
 // contractions of ALL of them go out as one grouped launch of wgrad.hip's kernel (one workgroup per CU, the K slices being
 // what is left after the tiles: 3 nets = 36 tiles x 7 slices instead of 12 launches x 512 workgroups of split-K atomics).
-extern "C" int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* bds, int n, void* stream) {
-  FH_CHECK_PTR(bds);
-  if (n < 0) return FHVAE_ERR_SHAPE;
+static bool wg_from_desc(const fhvae_wgrad_desc* x, WgProblem& p) {
+  if (!x || x->M <= 0 || x->N <= 0 || x->K <= 0 || x->M > INT32_MAX || x->N > INT32_MAX || x->K > INT32_MAX || x->a_col0 < 0 ||
+      x->a_col0 > INT32_MAX)
+    return false;
+  p = WgProblem{};
+  p.A = (const u16*)x->a, p.B = (const u16*)x->b, p.C = x->c;
+  p.lda = x->lda, p.ldb = x->ldb, p.ldc = x->ldc;
+  p.M = (int)x->M, p.N = (int)x->N, p.K = (int)x->K;
+  p.a_col0 = (int)x->a_col0;
+  return wgrad_eligible(p) && x->ldc >= x->N;
+}
+
+extern "C" int fhvae_wgrad_desc_ok(const fhvae_wgrad_desc* x) {
+  WgProblem p;
+  return wg_from_desc(x, p) ? 1 : 0;
+}
+
+extern "C" int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* bds, int n, const fhvae_wgrad_desc* extra, int n_extra,
+                                            void* stream) {
+  if (n < 0 || n_extra < 0) return FHVAE_ERR_SHAPE;
+  if (n > 0) FH_CHECK_PTR(bds);
+  if (n_extra > 0) FH_CHECK_PTR(extra);
   hipStream_t st = (hipStream_t)stream;
   std::vector<WgProblem> wq;
+  for (int i = 0; i < n_extra; ++i) {
+    WgProblem p;
+    if (!wg_from_desc(extra + i, p)) return FHVAE_ERR_ALIGN;
+    wq.push_back(p);
+  }
   std::vector<GemmParams> fq;  // the f32 (B-row) contractions of the time-constant inputs
   const bool use_wq = !getenv("FHVAE_NO_WGRAD");
   for (int i = 0; i < n; ++i) {

@@ -13,6 +13,7 @@ struct WgProblem {
   // filled by launch_wgrad
   int m_tiles, n_tiles, splitk, ksteps_per;
   int shared_c;  // another problem of the same launch accumulates into the same C: atomics even without a K split
+  int a_col0;    // A points a_col0 columns INTO the rows of its buffer (a column slice): the buffer ends that much earlier
 };
 
 constexpr int kMaxWgProblems = 16;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(WgGroup g) {
   // M / N inside a row read the neighbouring bytes (in bounds) and only feed output columns that are never stored
   const unsigned lda_b = (unsigned)p.lda * 2u, ldb_b = (unsigned)p.ldb * 2u;
   const __amdgpu_buffer_rsrc_t rsa =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.A + m0), 0, (int)(((int64_t)p.K * p.lda - m0) * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.A + m0), 0, (int)(((int64_t)p.K * p.lda - p.a_col0 - m0) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsb =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.B + n0), 0, (int)(((int64_t)p.K * p.ldb - n0) * 2), 0x00020000);
   unsigned va[IA::NI], vb[IB::NI];
@@ -223,7 +223,7 @@ template __global__ void wgrad_kernel<128>(WgGroup);
 bool wgrad_eligible(const WgProblem& p) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.B || !p.C) return false;
   if ((((uintptr_t)p.A) | ((uintptr_t)p.B)) & 15) return false;
-  if ((p.lda % 8) || (p.ldb % 8) || p.lda < p.M || p.ldb < p.N) return false;
+  if ((p.lda % 8) || (p.ldb % 8) || p.lda < p.a_col0 + p.M || p.ldb < p.N || p.a_col0 < 0) return false;
   // 32-bit buffer offsets / num_records
   if ((int64_t)p.K * p.lda * 2 >= (1LL << 30) || (int64_t)p.K * p.ldb * 2 >= (1LL << 30)) return false;
   return true;

@@ -113,10 +113,13 @@ class FHVAE(FHVAEBase):
         x_tm = hb.to_time_major(x, with_bf16=dt == hb.BF16)  # (T,B,F): contiguous per-step tiles for the step-fused cells
         # the encoders only use their final states; in bf16 mode the decoder's per-frame head reads the bf16 states, so the
         # f32 copy of the per-step states is not written at all (top=0 / top=1)
+        # bf16 mode: the latent heads contract bf16 copies of the final states too (the nets that produced them ran on bf16
+        # operands; hip_binding.gauss_head's condition on the sizes)
+        lp = (lambda h, dim: hb.cast_bf16(h) if (dt == hb.BF16 and h.shape[1] % 8 == 0 and dim % 8 == 0) else None)
         _, hn2 = self.z2_pre_encoder(x_tm, None, T, dt, top=0)
-        z2_mu, z2_logvar, z2_sample = self.z2_gauss_layer(hn2, e2)
+        z2_mu, z2_logvar, z2_sample = self.z2_gauss_layer(hn2, e2, input_lp=lp(hn2, self.z2_dim))
         _, hn1 = self.z1_pre_encoder(x_tm, z2_sample, T, dt, top=0)
-        z1_mu, z1_logvar, z1_sample = self.z1_gauss_layer(hn1, e1)
+        z1_mu, z1_logvar, z1_sample = self.z1_gauss_layer(hn1, e1, input_lp=lp(hn1, self.z1_dim))
         lp_head = dt == hb.BF16 and self.x_hus[-1] % 8 == 0 and F_ % 8 == 0  # (hip_binding.gauss_head's condition)
         hs_top, _ = self.pre_decoder(None, torch.cat([z1_sample, z2_sample], dim=-1), T, dt, top=1 if lp_head else 2)
         H = hs_top.shape[-1]

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
 
 F32, BF16 = 0, 1
 MAX_LAYERS = 4
-ABI_VERSION = 7  # FHVAE_ABI_VERSION of include/fhvae_hip.h
+ABI_VERSION = 8  # FHVAE_ABI_VERSION of include/fhvae_hip.h
 #: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
 INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
@@ -68,7 +68,13 @@ class ElboBwdDesc(C.Structure):
         ("reference_detach", _i32),
         ("d_x_mu", _vp), ("d_x_lv", _vp), ("d_z1_mu", _vp), ("d_z1_lv", _vp), ("d_z2_mu", _vp), ("d_z2_lv", _vp),
         ("d_mu2", _vp),
+        ("d_x_pair_lp", _vp), ("ld_pair", _i64), ("d_x_colsum", _vp),
     ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("a", _vp), ("lda", _i64), ("a_col0", _i64), ("b", _vp), ("ldb", _i64), ("c", _vp), ("ldc", _i64),
+                ("M", _i64), ("N", _i64), ("K", _i64)]
 
 
 #: every symbol include/fhvae_hip.h declares: name -> (restype, argtypes)
@@ -83,7 +89,11 @@ SIGNATURES = {
     "fhvae_gauss_head_pair_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "fhvae_gauss_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fhvae_gauss_head_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
-    "fhvae_gauss_head_bwd_lp": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_head_pair_weights": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_gauss_reparam_pair_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "fhvae_gauss_reparam_bwd_pair": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_elbo_colsum_rows": (_i64, [_i64]),
+    "fhvae_gauss_head_bwd_pair": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_loss_fwd": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _vp, _vp]),
     "fhvae_loss_bwd": (C.c_int, [_vp, _f32, _vp, _vp, _i64, _vp]),
     "fhvae_lstm_lp_bytes": (_i64, [C.POINTER(LstmDesc)]),
@@ -93,7 +103,8 @@ SIGNATURES = {
     "fhvae_lstm_ws_below_elems": (_i64, [C.POINTER(LstmDesc)]),
     "fhvae_lstm_seq_fwd": (C.c_int, [C.POINTER(LstmDesc), _vp]),
     "fhvae_lstm_seq_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), _vp]),
-    "fhvae_lstm_param_grads_multi": (C.c_int, [C.POINTER(C.POINTER(LstmBwdDesc)), C.c_int, _vp]),
+    "fhvae_lstm_param_grads_multi": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp]),
+    "fhvae_wgrad_desc_ok": (C.c_int, [_vp]),
     "fhvae_wgrad_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
     "fhvae_proj_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
@@ -167,20 +178,23 @@ LSTM_BWD_REC_HOOK = {"fn": None}
 # 256x256 tiles with a few K slices instead of 12 launches of 512 split-K workgroups each.
 # A caller that reads `param.grad` between backward() and the optimizer must call flush_param_grads() first.
 # ---------------------------------------------------------------------------------------------
-_DEFER = {"enabled": not os.environ.get("FHVAE_NO_DEFER"), "pending": []}
+# "extra": the heads' weight-gradient contractions (WgradDesc, keep-alive tensors), which ride in the same grouped launch
+_DEFER = {"enabled": not os.environ.get("FHVAE_NO_DEFER"), "pending": [], "extra": []}
 
 
 def flush_param_grads():
     """Run the queued parameter-gradient phases (current stream).  No-op when nothing is queued."""
-    pend = _DEFER["pending"]
-    if not pend:
+    pend, extra = _DEFER["pending"], _DEFER["extra"]
+    if not pend and not extra:
         return
     lib = load_library()
-    n = len(pend)
-    arr = (C.POINTER(LstmBwdDesc) * n)(*[C.pointer(bd) for bd, _ in pend])
+    n, nx = len(pend), len(extra)
+    arr = (C.POINTER(LstmBwdDesc) * n)(*[C.pointer(bd) for bd, _ in pend]) if n else None
+    xs = (WgradDesc * nx)(*[x for x, _ in extra]) if nx else None
     with _Timed("fhvae_lstm_param_grads_multi"):
-        _check(lib.fhvae_lstm_param_grads_multi(arr, n, _stream()), "fhvae_lstm_param_grads_multi")
+        _check(lib.fhvae_lstm_param_grads_multi(arr, n, xs, nx, _stream()), "fhvae_lstm_param_grads_multi")
     pend.clear()  # (the caching allocator keeps the released buffers ordered behind this stream's queued work)
+    extra.clear()
 
 
 def flush_param_grads_except_last():
@@ -443,9 +457,24 @@ class _GaussHead(torch.autograd.Function):
         return dh, dw_mu, db_mu, dw_lv, db_lv, None
 
 
+# The upstream gradient of a head's (mu | logvar) pair buffer can arrive ready-made: fhvae_elbo_bwd writes the decoder-output
+# gradients a second time as the bf16 operand of the head's backward contractions, with their column sums (the bias
+# gradients).  _Elbo.backward leaves them here under the address of the f32 gradient buffer it returns to autograd; the head's
+# backward takes them only when the gradients autograd hands it ARE that buffer (same address and strides: nothing was
+# accumulated into or cast from it on the way).  One entry: the latest.
+_PAIR_GRAD: dict = {}
+PAIR_SIDE = {"enabled": True, "used": 0}  # tests: switch the ready-made operand off / count how often a head took it
+
+
+def _pair_ld(D: int) -> int:
+    return (2 * D + 63) // 64 * 64  # whole 64-k stages of the projection kernel; the padding is zero
+
+
 class _GaussHeadLp(torch.autograd.Function):
-    """_GaussHead with bf16 MFMA operands: `h` (f32) only carries the gradient, the contraction reads `h_lp` (the same
-    values in bf16) and bf16 copies of the weights; outputs, gradients and accumulation are f32."""
+    """_GaussHead with bf16 MFMA operands: `h` (f32) only carries the gradient, the contractions read `h_lp` (the same
+    values in bf16) and stacked bf16 copies of the two weight matrices: mu | logvar come out of ONE projection side by side,
+    and the backward is one projection (dh), one weight-gradient launch and a column sum over one bf16 operand
+    g = [g_mu | g_lv].  Outputs, gradients and accumulation are f32."""
 
     @staticmethod
     def forward(ctx, h, h_lp, w_mu, b_mu, w_lv, b_lv, eps):
@@ -458,29 +487,24 @@ class _GaussHeadLp(torch.autograd.Function):
         D = w_mu.shape[0]
         assert h_lp.dtype == torch.bfloat16 and h_lp.is_contiguous() and h.shape == h_lp.shape
         dev = h_lp.device
-        wl = torch.empty(2, D, K, device=dev, dtype=torch.bfloat16)     # bf16 weights
-        wt = torch.empty(2, K, D, device=dev, dtype=torch.bfloat16)     # ... and their transposes (backward's KC operands)
-        for i, w in enumerate((w_mu, w_lv)):
-            _check(lib.fhvae_cast_bf16(_p(w), _p(wl[i]), _p(wt[i]), D, K, _stream()), "fhvae_cast_bf16")
-        eps = _f32c(eps) if eps is not None else None
-        if eps is None:
-            # no sampling (the per-frame decoder head): mu | logvar side by side from ONE projection over the stacked weights
-            out = torch.empty(M, 2 * D, device=dev, dtype=torch.float32)
-            with _Timed("fhvae_gauss_head_reparam_fwd"):
-                _check(lib.fhvae_gauss_head_pair_fwd(_p(h_lp), K, _p(wl), _p(b_mu), _p(b_lv), _p(out), 2 * D, M, K, D, _stream()),
-                       "fhvae_gauss_head_pair_fwd")
-            mu, lv, smp = out[:, :D], out[:, D:], None
-        else:
-            mu = torch.empty(M, D, device=dev, dtype=torch.float32)
-            lv = torch.empty_like(mu)
-            smp = torch.empty_like(mu)
-            with _Timed("fhvae_gauss_head_reparam_fwd"):
-                _check(lib.fhvae_gauss_head_reparam_fwd(_p(h_lp), K, _p(wl[0]), _p(wl[1]), _p(b_mu), _p(b_lv), _p(eps), _p(mu), _p(lv),
-                                                        _p(smp), M, K, D, BF16, _stream()), "fhvae_gauss_head_reparam_fwd")
+        ldg = _pair_ld(D)
+        wl = torch.empty(2 * D, K, device=dev, dtype=torch.bfloat16)   # [W_mu; W_lv]
+        wt = torch.empty(K, ldg, device=dev, dtype=torch.bfloat16)     # [W_mu^T | W_lv^T | 0]: the backward's operand
+        _check(lib.fhvae_head_pair_weights(_p(w_mu), _p(w_lv), _p(wl), _p(wt), ldg, D, K, _stream()), "fhvae_head_pair_weights")
+        out = torch.empty(M, 2 * D, device=dev, dtype=torch.float32)
+        with _Timed("fhvae_gauss_head_reparam_fwd"):
+            _check(lib.fhvae_gauss_head_pair_fwd(_p(h_lp), K, _p(wl), _p(b_mu), _p(b_lv), _p(out), 2 * D, M, K, D, _stream()),
+                   "fhvae_gauss_head_pair_fwd")
+            if eps is not None:  # a sampling head (the latents): contiguous mu, logvar and the sample from one more small launch
+                eps = _f32c(eps)
+                mu, lv, smp = (torch.empty(M, D, device=dev, dtype=torch.float32) for _ in range(3))
+                _check(lib.fhvae_gauss_reparam_pair_fwd(_p(out), 2 * D, _p(eps), _p(smp), _p(mu), _p(lv), M, D, _stream()),
+                       "fhvae_gauss_reparam_pair_fwd")
+            else:  # the per-frame head: mu | logvar stay side by side (the lower bound reads them in place)
+                mu, lv = out[:, :D], out[:, D:]
+                smp = mu.new_empty(())  # placeholder (value never read)
+                ctx.mark_non_differentiable(smp)
         ctx.save_for_backward(h_lp, wt, eps, lv)
-        if smp is None:
-            smp = mu.new_empty(())  # placeholder (value never read)
-            ctx.mark_non_differentiable(smp)
         return mu, lv, smp
 
     @staticmethod
@@ -491,20 +515,41 @@ class _GaussHeadLp(torch.autograd.Function):
             d_s = None
         M, D = lv.shape
         K = h_lp.shape[1]
-        d_mu = _f32c(d_mu) if d_mu is not None else None
-        d_lv = _f32c(d_lv) if d_lv is not None else None
-        d_s = _f32c(d_s) if d_s is not None else None
+        ldg = wt.shape[1]
         need_dh = ctx.needs_input_grad[0]
         sk = ctx.sinks
         dev = h_lp.device
         outs = [k if k is not None else torch.zeros(shape, device=dev, dtype=torch.float32)
                 for k, shape in zip(sk, ((D, K), (D,), (D, K), (D,)))]
-        g_lp = torch.empty(M, 2 * D, device=dev, dtype=torch.bfloat16)
         dh = torch.empty(M, K, device=dev, dtype=torch.float32) if need_dh else None
+        g_lp = colsum = None
+        ready = _PAIR_GRAD.get("latest")
+        if (ready is not None and d_s is None and d_mu is not None and d_lv is not None and ready[0] == d_mu.data_ptr()
+                and d_lv.data_ptr() == ready[0] + 4 * D and d_mu.shape == (M, D) and d_lv.shape == (M, D)
+                and d_mu.stride() == (2 * D, 1) and d_lv.stride() == (2 * D, 1) and ready[1].shape == (M, ldg)):
+            g_lp, colsum = ready[1], ready[2]
+            _PAIR_GRAD.clear()
+            PAIR_SIDE["used"] += 1
         with _Timed("fhvae_gauss_head_bwd"):
-            _check(lib.fhvae_gauss_head_bwd_lp(_p(h_lp), K, _p(wt[0]), _p(wt[1]), _p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), _p(g_lp),
-                                               _p(dh), K, _p(outs[0]), _p(outs[2]), _p(outs[1]), _p(outs[3]), M, K, D, _stream()),
-                   "fhvae_gauss_head_bwd_lp")
+            if g_lp is None:
+                d_mu = _f32c(d_mu) if d_mu is not None else None
+                d_lv = _f32c(d_lv) if d_lv is not None else None
+                d_s = _f32c(d_s) if d_s is not None else None
+                g_lp = torch.empty(M, ldg, device=dev, dtype=torch.bfloat16)
+                _check(lib.fhvae_gauss_reparam_bwd_pair(_p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), lv.stride(0), _p(g_lp), ldg, M, D,
+                                                        _stream()), "fhvae_gauss_reparam_bwd_pair")
+            # every parameter has a gradient sink: the two weight-gradient contractions join the nets' grouped launch
+            xs = None
+            if _DEFER["enabled"] and not _SIDE["enabled"] and all(k is not None for k in sk):
+                xs = [WgradDesc(_p(g_lp) + 2 * i * D, ldg, i * D, _p(h_lp), K, _p(outs[2 * i]), K, D, K, M) for i in range(2)]
+                if not all(lib.fhvae_wgrad_desc_ok(C.byref(x)) for x in xs):
+                    xs = None
+            dws = (None, None) if xs is not None else (outs[0], outs[2])
+            _check(lib.fhvae_gauss_head_bwd_pair(_p(h_lp), K, _p(wt), ldg, _p(g_lp), ldg, _p(colsum), colsum.shape[0] if colsum is not None else 0, _p(dh), K,
+                                                 _p(dws[0]), _p(dws[1]),
+                                                 _p(outs[1]), _p(outs[3]), M, K, D, _stream()), "fhvae_gauss_head_bwd_pair")
+            if xs is not None:
+                _DEFER["extra"].extend((x, (g_lp, h_lp, outs[0], outs[2])) for x in xs)
         dw_mu, db_mu, dw_lv, db_lv = (None if k is not None else o for k, o in zip(sk, outs))
         return dh, None, dw_mu, db_mu, dw_lv, db_lv, None
 
@@ -516,6 +561,16 @@ def gauss_head(h, w_mu, b_mu, w_lv, b_lv, eps, h_lp=None):
     else:
         mu, lv, smp = _GaussHead.apply(h, w_mu, b_mu, w_lv, b_lv, eps)
     return mu, lv, (smp if eps is not None else None)
+
+
+def cast_bf16(t: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of a contiguous f32 matrix (one launch; no gradient): the operand of a bf16 head."""
+    _need_gpu(t)
+    t = _f32c(t.detach())
+    out = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    R = t.shape[0]
+    _check(load_library().fhvae_cast_bf16(_p(t), _p(out), None, R, t.numel() // R, _stream()), "fhvae_cast_bf16")
+    return out
 
 
 def to_time_major(x: torch.Tensor, with_bf16: bool = False):
@@ -855,9 +910,16 @@ class _Elbo(torch.autograd.Function):
         bd.g_lower_bound, bd.g_log_px_z, bd.g_neg_kld_z1, bd.g_neg_kld_z2, bd.g_log_pmu2 = (_p(g) for g in gs)
         bd.reference_detach = int(ctx.detach)
         need_x = not ctx.detach
+        side = None
         if need_x and ctx.pair:
             dbuf = torch.empty(ts[1].shape[0], 2 * F_, device=ts[1].device, dtype=torch.float32)
             d_xmu, d_xlv = dbuf[:, :F_], dbuf[:, F_:]
+            # time-major rows, whole float4 groups: the kernel also leaves the bf16 operand + column sums for the head's backward
+            if PAIR_SIDE["enabled"] and xs == (F_, B * F_) and F_ % 4 == 0 and F_ <= 256 and ts[0].data_ptr() % 16 == 0 and ts[1].data_ptr() % 16 == 0:
+                ldg = _pair_ld(F_)
+                side = (dbuf.data_ptr(), torch.empty(T * B, ldg, device=dbuf.device, dtype=torch.bfloat16),
+                        torch.empty(int(lib.fhvae_elbo_colsum_rows(B)), 2 * F_, device=dbuf.device, dtype=torch.float32))
+                bd.d_x_pair_lp, bd.ld_pair, bd.d_x_colsum = _p(side[1]), ldg, _p(side[2])
         else:
             d_xmu = torch.empty_like(ts[1]) if need_x else None
             d_xlv = torch.empty_like(ts[2]) if need_x else None
@@ -866,6 +928,8 @@ class _Elbo(torch.autograd.Function):
         bd.d_z1_mu, bd.d_z1_lv, bd.d_z2_mu, bd.d_z2_lv, bd.d_mu2 = (_p(t) for t in dz)
         with _Timed("fhvae_elbo_bwd"):
             _check(lib.fhvae_elbo_bwd(C.byref(bd), _stream()), "fhvae_elbo_bwd")
+        if side is not None:
+            _PAIR_GRAD["latest"] = side
         return (None, d_xmu, d_xlv, *dz, None, None, None)
 
 

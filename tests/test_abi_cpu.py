@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), "libfhvae_hip.so lacks %s" % n
         assert n in hb.SIGNATURES, "hip_binding does not bind %s" % n
     assert set(hb.SIGNATURES) == set(names)
-    assert lib.fhvae_abi_version() == 7
+    assert lib.fhvae_abi_version() == 8
     assert lib.fhvae_strerror(-1) == b"required pointer is NULL"
 
 
@@ -47,7 +47,7 @@ def test_struct_layouts_match_header(lib):
     assert ctypes.sizeof(hb.LstmDesc) == 8 + 5 * 8 + 3 * 8 + 4 * 4 * 8 + 8 * 8
     assert ctypes.sizeof(hb.LstmBwdDesc) == ctypes.sizeof(hb.LstmDesc) + 5 * 8 + 4 * 4 * 8 + 8 + 8 + 8
     assert ctypes.sizeof(hb.ElboDesc) == 5 * 8 + 3 * 8 + 4 * 8 + 5 * 8 + 2 * 8 + 5 * 8
-    assert ctypes.sizeof(hb.ElboBwdDesc) == ctypes.sizeof(hb.ElboDesc) + 5 * 8 + 8 + 7 * 8
+    assert ctypes.sizeof(hb.ElboBwdDesc) == ctypes.sizeof(hb.ElboDesc) + 5 * 8 + 8 + 7 * 8 + 3 * 8
 
 
 def test_argument_errors_are_reported_before_any_launch(lib):

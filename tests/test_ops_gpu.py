@@ -80,6 +80,73 @@ def test_gauss_head(hb):
     close(mud2, mu, what="mu(nosample)")
 
 
+@pytest.mark.parametrize("M,K,D,sample", [(37, 96, 16, True), (2048, 512, 32, True), (4100, 256, 80, False), (300, 64, 8, False),
+                                          (1000, 128, 40, True)])
+def test_gauss_head_bf16_operands(hb, M, K, D, sample):
+    """The bf16-operand head (hip_binding._GaussHeadLp: stacked weights, one projection each way, csrc/proj.hip + wgrad.hip where
+    the shape allows, the generic engine otherwise) against torch autograd on the SAME bf16-rounded operands in f64: outputs
+    1e-4 of their scale (f32 accumulation), gradients 2e-2 (the upstream gradient is itself rounded to bf16)."""
+    torch.manual_seed(M + K)
+    rb = lambda t: t.bfloat16().double()
+    h = torch.randn(M, K)
+    wm, wl = torch.randn(D, K) * 0.1, torch.randn(D, K) * 0.1
+    bm, bl = torch.randn(D), torch.randn(D)
+    eps = torch.randn(M, D) if sample else None
+    gm, gl, gs = torch.randn(M, D), torch.randn(M, D), torch.randn(M, D)
+    ref = [t.requires_grad_(True) for t in (rb(h), rb(wm), bm.double(), rb(wl), bl.double())]
+    mu, lv = torch.nn.functional.linear(ref[0], ref[1], ref[2]), torch.nn.functional.linear(ref[0], ref[3], ref[4])
+    tot = (mu * gm.double()).sum() + (lv * gl.double()).sum()
+    if sample:
+        smp = mu + eps.double() * torch.exp(0.5 * lv)
+        tot = tot + (smp * gs.double()).sum()
+    tot.backward()
+    args = [dev(t).requires_grad_(True) for t in (h, wm, bm, wl, bl)]
+    mud, lvd, sd = hb.gauss_head(*args, dev(eps) if sample else None, h_lp=dev(h).bfloat16())
+    totd = (mud * dev(gm)).sum() + (lvd * dev(gl)).sum()
+    if sample:
+        totd = totd + (sd * dev(gs)).sum()
+    totd.backward()
+    outs = [(mud, mu, "mu"), (lvd, lv, "lv")] + ([(sd, smp, "sample")] if sample else [])
+    for got, want, n in outs:
+        assert _max_rel(got, want) < 1e-4, (n, _max_rel(got, want))
+    for a, r, n in zip(args, ref, "h wm bm wl bl".split()):
+        assert _max_rel(a.grad, r.grad) < 2e-2, ("d" + n, _max_rel(a.grad, r.grad))
+
+
+def test_head_takes_the_lower_bound_kernels_bf16_gradient(hb):
+    """Per-frame head + lower bound, time-major (T*B, F) rows: fhvae_elbo_bwd leaves [d_x_mu | d_x_lv] in bf16 with the column
+    sums, and the head's backward takes them (no second pass over the f32 gradients).  Same parameter gradients and dh as with
+    the hand-over switched off (the head then rounds the f32 gradients itself: identical bf16 operand; the bias gradients are
+    sums of the f32 values in one case and of the rounded ones in the other: 2e-3)."""
+    torch.manual_seed(3)
+    T, B, F, K, D2 = 20, 96, 80, 256, 16
+    x = dev(torch.randn(T, B, F))
+    h = dev(torch.randn(T * B, K))
+    w = [dev(t) for t in (torch.randn(F, K) * 0.05, torch.randn(F) * 0.1, torch.randn(F, K) * 0.05, torch.randn(F) * 0.1)]
+    z = [dev(torch.randn(B, D2)) for _ in range(5)]
+    ns = dev(torch.randint(20, 100, (B,)))
+    layout = (B, T, F, (F, B * F), (F, B * F))
+
+    def run(side):
+        hb.PAIR_SIDE["enabled"] = side
+        used0 = hb.PAIR_SIDE["used"]
+        try:
+            hh = h.clone().requires_grad_(True)
+            ws = [t.clone().requires_grad_(True) for t in w]
+            x_mu, x_lv, _ = hb.gauss_head(hh, *ws, None, h_lp=hh.detach().bfloat16())
+            lb = hb.elbo(x, x_mu, x_lv, *z, ns, layout, False)[0]
+            (lb * dev(torch.linspace(0.5, 1.5, B))).sum().backward()
+            torch.cuda.synchronize()
+            assert hb.PAIR_SIDE["used"] - used0 == (1 if side else 0)
+            return [hh.grad] + [t.grad for t in ws]
+        finally:
+            hb.PAIR_SIDE["enabled"] = True
+
+    a, b = run(True), run(False)
+    for u, v, n in zip(a, b, "dh dwm dbm dwl dbl".split()):
+        assert _max_rel(u, v) < 2e-3, (n, _max_rel(u, v))
+
+
 def _max_rel(got, want):
     got, want = got.detach().cpu().double(), want.detach().cpu().double()
     return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
