@@ -346,7 +346,10 @@ int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp, const floa
  * w = g*(p - [s == idx[b]-row0])
  *   dq[b,:]     = sum_s w * (-2 c)(q[b]-t[s])      OVERWRITTEN  (partial over this shard's rows)
  *   dtable[s,:] += sum_b w * (+2 c)(q[b]-t[s])     ACCUMULATED
- * g is read from device memory (g_scale, one f32) so the call stays graph-capturable. */
+ * g is read from device memory (g_scale, one f32) so the call stays graph-capturable.
+ * ws: fhvae_disc_lse_bwd_ws_bytes(B,S,D) bytes of workspace (16-byte aligned), or NULL.  With it (and dq and dtable both wanted) the kernels that
+ * have a one-pass form take both gradients from ONE recomputation of the logits; without it, one pass per gradient. */
+int64_t fhvae_disc_lse_bwd_ws_bytes(int64_t B, int64_t S, int64_t D);
 int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
                        float inv_two_var, const float* row_max, const float* row_sumexp,
                        const float* g_scale, float g_mul, float* dq, float* dtable, void* ws,

@@ -61,23 +61,43 @@ __device__ __forceinline__ bf16x8 frag_t(const char* img, int row0, int dj, int 
   return u.v;
 }
 
-// XQ: the stationary set is the queries (forward, dq); else the table rows (dtable)
+// XQ: the stationary set is the queries (forward, dq); else the table rows (dtable).
+// MODE 2 (XQ only) = MODE 1 plus the STREAMED side's gradient from the same weights: both backward products from one
+// recomputation of the logits and one exp per pair.  G2[y][d] += 2c sum_x w[y,x] X[x][d] needs w with x on the contraction
+// index, i.e. transposed: each wave leaves its bf16 weights of a 32-row block in a private [x][y] LDS image (ds_write_b64: the 4
+// accumulator registers of a tile are 4 consecutive y) and reads them back as A fragments with ds_read_b64_tr_b16 (frag_t:
+// the image is the [k][m] layout that read expects).  B = the wave's own 64 stationary vectors as [k = x][n = d] fragments in
+// the k order of frag_t (hi / lo split), kept in registers; a third B operand of ones gives WY[y] = sum_x w[y,x] from the same
+// rounded weights.  Each wave leaves its partial tiles in an LDS slot of its own; the four slots are summed after each 64-row tile.
+// No global atomics in this mode (the chip retires ~70 G f32 atomics/s: (B/256) S D of them would cost more than the second
+// pass they replace): both sides leave PARTIALS with plain stores -- G[chunk][x][d] and G2[x-tile][y][d], WY[x-tile][y] -- and
+// two small kernels (disc_mfma.hip) reduce them: dq = sum over chunks; dtable += 2c (sum G2 - t_y sum WY).
+constexpr int kDtLd = 36;  // row stride of the LDS accumulator (floats): rows 4 apart fall into different banks
 template <int MODE, bool XQ>
 __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
+  static_assert(MODE != 2 || XQ, "the one-pass backward keeps the queries stationary");
+  constexpr bool BW = MODE >= 1;     // backward: weights + the stationary side's product
+  constexpr bool BOTH = MODE == 2;   // ... and the streamed side's
+  __shared__ __attribute__((aligned(16))) char wimg[BOTH ? 4 : 1][BOTH ? 64 * 64 : 16];  // per wave: [x = 64][y = 32] bf16
+  __shared__ float wy_lds[BOTH ? 4 : 1][BOTH ? kYT : 1];  // per wave
   __shared__ __attribute__((aligned(16))) char yhi[kYT * kD * 2];
   __shared__ __attribute__((aligned(16))) char ylo[kYT * kD * 2];
   __shared__ __attribute__((aligned(16))) float yn[kYT];
   __shared__ float ymax[kYT], yinv[kYT];
   __shared__ int ytgt[kYT];
   __shared__ int yown[kYT / 32][4];  // !XQ: wave w staged a query of block b whose target is one of this workgroup's rows
-  __shared__ float tr[MODE == 1 ? 256 : 1][MODE == 1 ? kD + 1 : 1];
+  // backward epilogue: the transpose buffer tr[256][D + 1]; MODE 2, inside the loop: one [64 y][kDtLd] slot per wave for its
+  // partial of the streamed side's product (plain writes; LDS float atomics from 8 waves cost more than the second pass did)
+  constexpr int kRed = !BW ? 1 : (BOTH && 4 * kYT * kDtLd > 256 * (kD + 1) ? 4 * kYT * kDtLd : 256 * (kD + 1));
+  __shared__ __attribute__((aligned(16))) float red[kRed];
+  float (*tr)[kD + 1] = (float (*)[kD + 1]) red;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, i = lane & 15;
   const int x0 = blockIdx.y * 256 + wave * 64;
   const int y_begin = blockIdx.x * a.chunk;
   const int y_end = min(a.NY, y_begin + a.chunk);
-  const float gscale = MODE == 1 ? (*a.gsc) * a.gmul : 0.f;
+  const float gscale = BW ? (*a.gsc) * a.gmul : 0.f;
 
   // ---- stationary fragments (B operand of the logit product): lane (g,i) of tile t holds X[x0+16t+i][8g .. 8g+7], split
   bf16x8 xh[4], xl[4];
@@ -108,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
       if (ok) {
         const int64_t tg = a.idx[x] - a.row0;
         xtgt[t] = (tg >= 0 && tg < a.NY) ? (int)tg : -1;
-        if (MODE == 1) {
+        if (BW) {
           xmax[t] = a.rmax[x];
           xinv[t] = gscale / a.rsum[x];  // (the upstream scale rides on the normaliser)
         }
@@ -116,6 +136,31 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
     } else {
       xtgt[t] = ok ? x : -2;  // table row index: a streamed query hits it when its target == x
     }
+  }
+
+  // MODE 2: B fragments of the streamed side's product: k = x in frag_t's order (rows 4g..4g+3 and 16+4g..16+4g+3 of the
+  // 32-vector block kb), n = d = 16 dj + i
+  bf16x8 xbh[BOTH ? 2 : 1][2], xbl[BOTH ? 2 : 1][2], ones;
+  if constexpr (BOTH) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int x = x0 + 32 * kb + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+          v[j] = x < a.NX ? a.X[(int64_t)x * kD + 16 * dj + i] : 0.f;
+        }
+        split8(v, xbh[kb][dj], xbl[kb][dj]);
+      }
+    union {
+      u16 h[8];
+      bf16x8 v;
+    } o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.h[j] = 0x3F80;  // bf16(1.0)
+    ones = o.v;
   }
 
   float m[4], ssum[4], wsum[4];
@@ -212,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
       }
       // A fragments of the second product: Y^T (d on the rows), k = the block's 32 streamed rows
       bf16x8 th[2], tl[2];
-      if constexpr (MODE == 1) {
+      if constexpr (BW) {
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
           th[dj] = frag_t(yhi, yp * 32, dj, g, i);
@@ -273,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
             }
           }
         }
-        if constexpr (MODE == 1) {
+        if constexpr (BW) {
           // w in bf16 (k-slot 8g + j <-> row 4g + j of the first, 16 + 4g + (j - 4) of the second tile: the order of frag_t);
           // the weight sum takes the ROUNDED values (see the header)
           union {
@@ -290,6 +335,14 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
             gacc[t][dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th[dj], wb.v, gacc[t][dj], 0, 0, 0);
             gacc[t][dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tl[dj], wb.v, gacc[t][dj], 0, 0, 0);
           }
+          if constexpr (BOTH) {  // row x = 16t + i of the wave's [x][y] image: y = 16h + 4g .. + 3 are the 4 registers of tile h
+            char* wi = wimg[wave];
+            const int row = 16 * t + i;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              *(uint2*)(wi + img_off(row, 2 * h + (g >> 1)) + (g & 1) * 8) =
+                  uint2{(uint32_t)wb.h[4 * h] | ((uint32_t)wb.h[4 * h + 1] << 16), (uint32_t)wb.h[4 * h + 2] | ((uint32_t)wb.h[4 * h + 3] << 16)};
+          }
         }
       };
 #pragma unroll
@@ -301,8 +354,53 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
         else
           tile(t, std::false_type{});
       }
+      if constexpr (BOTH) {
+        // the streamed side's product over the wave's 64 stationary vectors (LDS operations of one wave complete in order: the
+        // reads below see the writes of the four tiles above)
+        // (a compiler-only ordering: a fence instruction would also wait for the prefetch of the next tile)
+        asm volatile("" ::: "memory");
+        const char* wi = wimg[wave];
+        f32x4 oacc[2][2], wya[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          oacc[h][0] = oacc[h][1] = wya[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            const bf16x8 wa = frag_t(wi, 32 * kb, h, g, i);  // A[m = y = 16h + i][k = x of block kb]
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+              oacc[h][dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xbh[kb][dj], oacc[h][dj], 0, 0, 0);
+              oacc[h][dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xbl[kb][dj], oacc[h][dj], 0, 0, 0);
+            }
+            wya[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, ones, wya[h], 0, 0, 0);
+          }
+        }
+        asm volatile("" ::: "memory");  // (the next block's writes stay behind these reads)
+        // lane holds out[y = 16h + 4g + r][d = 16dj + i] -> the wave's slot; WY is in every column: lane i == 0 stores it
+        float* slot = red + wave * (kYT * kDtLd);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int yr = yp * 32 + 16 * h + 4 * g + r;
+            slot[yr * kDtLd + i] = oacc[h][0][r];
+            slot[yr * kDtLd + 16 + i] = oacc[h][1][r];
+            if (i == 0) wy_lds[wave][yr] = wya[h][r];
+          }
+      }
     }
     __syncthreads();
+    if constexpr (BOTH) {  // the tile's four slots summed: plain stores into this x-tile's slice of the partial buffer (every
+                           // (x-tile, y) is written exactly once); the next tile's slot writes are behind its staging barrier
+      for (int e = tid; e < kYT * kD; e += 256) {
+        const int row = e / kD, d = e % kD, o = row * kDtLd + d;
+        if (y0 + row < y_end)
+          a.G2[((int64_t)blockIdx.y * a.NY + y0 + row) * kD + d] =
+              (red[o] + red[kYT * kDtLd + o]) + (red[2 * kYT * kDtLd + o] + red[3 * kYT * kDtLd + o]);
+      }
+      if (tid < kYT && y0 + tid < y_end)
+        a.WY[(int64_t)blockIdx.y * a.NY + y0 + tid] = (wy_lds[0][tid] + wy_lds[1][tid]) + (wy_lds[2][tid] + wy_lds[3][tid]);
+    }
   }
 
   if constexpr (MODE == 0) {
@@ -321,6 +419,7 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
       if (g == 0 && x < a.NX) a.part[(int64_t)blockIdx.x * a.NX + x] = make_float2(mm, ss);
     }
   } else {
+    if constexpr (BOTH) __syncthreads();  // (tr shares its memory with the slots the last tile's sums were read from)
     // grad_x = 2c (G - X W); lane holds G[x = 16t+i][d = 16dj + 4g + reg]; transpose through LDS -> row-contiguous atomics
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -341,7 +440,12 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
     for (int e = tid; e < 256 * kD; e += 256) {
       const int rr = e / kD, d = e % kD;
       const int x = blockIdx.y * 256 + rr;
-      if (x < a.NX) atomicAdd(a.G + (int64_t)x * kD + d, tr[rr][d]);
+      if (x < a.NX) {
+        if constexpr (BOTH)
+          a.G[((int64_t)blockIdx.x * a.NX + x) * kD + d] = tr[rr][d];  // this chunk's slice of the partial buffer
+        else
+          atomicAdd(a.G + (int64_t)x * kD + d, tr[rr][d]);
+      }
     }
   }
 }
@@ -351,6 +455,8 @@ __global__ __launch_bounds__(256, 2) void disc_lp_kernel(DiscMfmaArgs a) {
 void disc_lp_launch(const DiscMfmaArgs& a, int mode, dim3 grid, hipStream_t st) {
   if (mode == 0)
     hipLaunchKernelGGL((disc_lp_kernel<0, true>), grid, dim3(256), 0, st, a);
+  else if (mode == 2)
+    hipLaunchKernelGGL((disc_lp_kernel<2, true>), grid, dim3(256), 0, st, a);
   else if (a.x_is_query)
     hipLaunchKernelGGL((disc_lp_kernel<1, true>), grid, dim3(256), 0, st, a);
   else

@@ -19,6 +19,10 @@ struct DiscMfmaArgs {
   float gmul;
   float2* part;        // MODE 0: [nchunks][NX]
   float* G;            // MODE 1: [NX, D] accumulated with atomics
+  // MODE 2 (one pass, no atomics): G = partials [chunks][NX, D] of the stationary side's gradient; the streamed side's
+  // G2 = [x-tiles][NY, D] partial sums of w[y,x] X[x] and WY = [x-tiles][NY] of w[y,x] (reduced by disc_mfma.hip's kernels)
+  float* G2;
+  float* WY;
   int chunk;           // streamed vectors per workgroup (multiple of 64)
 };
 
@@ -30,8 +34,11 @@ int64_t disc_mfma_ws_bytes(int64_t B, int64_t S);
 // lp != 0: the bf16 split-operand kernels (D == 32 only; otherwise the f32 ones run)
 int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
                   int64_t B, int64_t S, int64_t D, int lp, hipStream_t st);
+// ws: disc_onepass_ws_bytes(B, S, D) of workspace (or NULL): with it, dq AND dtable wanted and a kernel that has the one-pass
+// form, both gradients come from one recomputation of the logits; otherwise one pass per gradient
+int64_t disc_onepass_ws_bytes(int64_t B, int64_t S, int64_t D);
 int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
-                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, int64_t B, int64_t S,
+                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, float* ws, int64_t B, int64_t S,
                   int64_t D, int lp, hipStream_t st);
 // disc_lp.hip
 void disc_lp_launch(const DiscMfmaArgs& a, int mode, dim3 grid, hipStream_t st);

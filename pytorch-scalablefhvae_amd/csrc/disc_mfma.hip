@@ -17,6 +17,7 @@
 // registers (row = 4*(lane>>4)+r): exactly the B-operand layout of the second product, so w never leaves registers.
 #include "disc_mfma.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace fh {
@@ -298,6 +299,33 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
   }
 }
 
+// the reductions of the one-pass backward's partials (disc_lp.hip, MODE 2)
+// dY[y][d] += 2c (sum_xt G2[xt][y][d] - Y[y][d] sum_xt WY[xt][y])
+__global__ void disc_dt_finish_kernel(float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ g2,
+                                      const float* __restrict__ wy, int nxt, float c2, int64_t NY, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NY * D) return;
+  const int64_t row = i / D;
+  float sg = 0.f, sw = 0.f;
+  for (int t = 0; t < nxt; ++t) {
+    sg += g2[(int64_t)t * NY * D + i];
+    sw += wy[(int64_t)t * NY + row];
+  }
+  dy[i] += c2 * (sg - y[i] * sw);
+}
+// dX[i] = sum_chunks G[chunk][i]
+__global__ void disc_dq_reduce_kernel(float* __restrict__ dx, const float* __restrict__ g, int nchunks, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    a0 += g[(int64_t)c * n + i], a1 += g[(int64_t)(c + 1) * n + i], a2 += g[(int64_t)(c + 2) * n + i], a3 += g[(int64_t)(c + 3) * n + i];
+  }
+  for (; c < nchunks; ++c) a0 += g[(int64_t)c * n + i];
+  dx[i] = (a0 + a1) + (a2 + a3);
+}
+
 // streamed vectors per workgroup for about `target` workgroups.  Forward (one partial per (chunk, x)): 1024.  Backward: every
 // workgroup adds its whole 256 x D partial gradient with atomics, so fewer, longer chunks pay (c2, S = 4600: 0.103 -> 0.078 ms per
 // step with 512; 384 and fewer lose on the large tables: S = 1M backward 6.4 ms with 512, 7.5 ms with 384)
@@ -315,6 +343,11 @@ bool disc_mfma_supported(int64_t B, int64_t S, int64_t D) { return (D == 32 || D
 int64_t disc_mfma_ws_bytes(int64_t B, int64_t S) {
   const int chunk = mfma_chunk(B, S);
   return fh_cdiv(S, chunk) * B * (int64_t)sizeof(float2);
+}
+
+int64_t disc_onepass_ws_bytes(int64_t B, int64_t S, int64_t D) {
+  const int64_t nchunks = fh_cdiv(S, mfma_chunk(B, S, 512)), nxt = fh_cdiv(B, 256);
+  return (nchunks * B * D + nxt * S * (D + 1)) * (int64_t)sizeof(float);
 }
 
 int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
@@ -342,7 +375,7 @@ int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_
 }
 
 int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
-                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, int64_t B, int64_t S,
+                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, float* ws, int64_t B, int64_t S,
                   int64_t D, int lp, hipStream_t st) {
   DiscMfmaArgs a = {};
   a.c = c;
@@ -352,6 +385,27 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
   a.rsum = rsum;
   a.gsc = gsc;
   a.gmul = gmul;
+  if (dq && dtable && ws && lp && D == 32 && !getenv("FHVAE_DISC_TWO_PASS")) {
+    // one pass: stationary = queries, streamed = table rows; dq as in the two-pass form, dtable from the same weights
+    a.X = q;
+    a.Y = table;
+    a.NX = (int)B;
+    a.NY = (int)S;
+    a.x_is_query = 1;
+    a.chunk = mfma_chunk(B, S, 512);
+    const int64_t nchunks = fh_cdiv(S, a.chunk), nxt = fh_cdiv(B, 256);
+    a.G = ws;                      // [nchunks][B, D]
+    a.G2 = a.G + nchunks * B * D;  // [nxt][S, D]
+    a.WY = a.G2 + nxt * S * D;     // [nxt][S]
+    dim3 grid((unsigned)nchunks, (unsigned)nxt);
+    disc_lp_launch(a, 2, grid, st);
+    int e = fh_launch_status();
+    if (e) return e;
+    hipLaunchKernelGGL(disc_dq_reduce_kernel, dim3((unsigned)fh_cdiv(B * D, 256)), dim3(256), 0, st, dq, a.G, (int)nchunks, B * D);
+    hipLaunchKernelGGL(disc_dt_finish_kernel, dim3((unsigned)fh_cdiv(S * D, 256)), dim3(256), 0, st, dtable, table, a.G2, a.WY, (int)nxt,
+                       2.f * c, S, (int)D);
+    return fh_launch_status();
+  }
   if (dq) {  // stationary = queries, streamed = table rows
     a.X = q;
     a.Y = table;

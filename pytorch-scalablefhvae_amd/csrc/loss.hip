@@ -819,6 +819,10 @@ extern "C" int fhvae_elbo_bwd(const fhvae_elbo_bwd_desc* d, void* stream) {
 // disc_mfma.hip / disc_lp.hip: the matrix-core forms for large (B x S), D == 32 (declared in disc_mfma.h)
   // namespace fh
 
+extern "C" int64_t fhvae_disc_lse_bwd_ws_bytes(int64_t B, int64_t S, int64_t D) {
+  return (B > 0 && S > 0 && D > 0 && disc_mfma_supported(B, S, D)) ? disc_onepass_ws_bytes(B, S, D) : 0;
+}
+
 extern "C" int64_t fhvae_elbo_colsum_rows(int64_t B) { return B > 0 ? fh_cdiv(B, 2) : 0; }
 
 extern "C" int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S) {
@@ -956,14 +960,13 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
   FH_CHECK_POS(S);
   FH_CHECK_I32(B);
   FH_CHECK_I32(S);
-  (void)ws;
   hipStream_t st = (hipStream_t)stream;
   if (disc_mfma_supported(B, S, D) && !getenv("FHVAE_DISC_VALU")) {
     if (dq) {
       hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
       if (he != hipSuccess) return (int)he;
     }
-    int e = disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, B, S, D,
+    int e = disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, (float*)ws, B, S, D,
                           dtype == FHVAE_BF16, st);
     if (e) return e;
     if (dq || dtable) {

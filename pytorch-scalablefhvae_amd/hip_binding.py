@@ -118,6 +118,7 @@ SIGNATURES = {
     "fhvae_elbo_fwd": (C.c_int, [C.POINTER(ElboDesc), _vp]),
     "fhvae_elbo_bwd": (C.c_int, [C.POINTER(ElboBwdDesc), _vp]),
     "fhvae_disc_lse_ws_bytes": (_i64, [_i64, _i64]),
+    "fhvae_disc_lse_bwd_ws_bytes": (_i64, [_i64, _i64, _i64]),
     "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
     "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
     "fhvae_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
@@ -991,9 +992,11 @@ def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True
     S = table.shape[0]
     dq = torch.empty(B, D, device=q.device, dtype=torch.float32) if need_dq else None
     dt = dt_sink if dt_sink is not None else (torch.zeros(S, D, device=q.device, dtype=torch.float32) if need_dt else None)
+    # workspace of the one-pass form (both gradients from one recomputation of the logits)
+    ws = torch.empty(max(int(lib.fhvae_disc_lse_bwd_ws_bytes(B, S, D)), 8), device=q.device, dtype=torch.uint8) if (need_dq and dt is not None) else None
     with _Timed("fhvae_disc_lse_bwd"):
         _check(lib.fhvae_disc_lse_bwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(g_scale), float(g_mul),
-                                      _p(dq), _p(dt), None, B, S, D, BF16 if lp else F32, _stream()), "fhvae_disc_lse_bwd")
+                                      _p(dq), _p(dt), _p(ws), B, S, D, BF16 if lp else F32, _stream()), "fhvae_disc_lse_bwd")
     return dq, (None if dt_sink is not None else dt)
 
 

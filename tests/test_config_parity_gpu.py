@@ -11,6 +11,8 @@ in the regime training converges to (queries next to their own table row, large 
 expansion 2c q.t - c|q|^2 - c|t|^2 cancels.
 Tolerances are written at each assert."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -307,6 +309,21 @@ def test_disc_converged_regime(hb, B, S, scale, noise):
                                              (300, 5000, 1.0, 0.05), (1024, 40000, 1.0, None),
                                              (512, 100000, 1.0, None), (256, 100000, 1.0, 0.05)])  # configs[3]'s table
 def test_disc_bf16_mode_vs_direct_f64(hb, B, S, scale, noise):
+    _disc_bf16_case(hb, B, S, scale, noise)
+
+
+@pytest.mark.parametrize("B,S,scale,noise", [(2048, 28000, 1.0, None), (300, 5000, 1.0, 0.05)])
+def test_disc_bf16_mode_two_pass_switch(hb, B, S, scale, noise):
+    """FHVAE_DISC_TWO_PASS=1: one recomputation of the logits per gradient (the form every call without a workspace takes)
+    instead of the one-pass backward; same tolerances."""
+    os.environ["FHVAE_DISC_TWO_PASS"] = "1"
+    try:
+        _disc_bf16_case(hb, B, S, scale, noise)
+    finally:
+        os.environ.pop("FHVAE_DISC_TWO_PASS", None)
+
+
+def _disc_bf16_case(hb, B, S, scale, noise):
     """K5 in the bf16 compute mode (hip_binding.disc_lse(..., lp=True): cross terms on bf16 MFMA with hi/lo-split operands,
     second products with bf16 weights; csrc/disc_lp.hip) against the direct form in float64.  Stated tolerance of that mode:
     the cross term carries ~2^-16 |q||t| (a logit: ~1e-3 absolute at N(0,1) scale, ~1e-2 at 3x), CE within 2e-3 relative +
