@@ -36,7 +36,7 @@ __device__ __forceinline__ int yoff(int row, int ch) {  // byte offset of 16-byt
 // combine kernel merges exp(target - max) into the row sum, the backward adds the pair's gradient in disc_own_bwd_kernel
 // (loss.hip).  CE -> log(1 + sum_others) and p_target - 1 -> -sum_others then come out cleanly however large the norms are.
 template <int D, int MODE>
-__global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
+__global__ __launch_bounds__(256, 2) void disc_mfma_kernel(DiscMfmaArgs a) {
   constexpr int CHN = D / 4;   // 16-byte chunks per vector
   constexpr int NJ = D / 16;   // 16-k groups (also 16-wide d blocks)
   constexpr int YT = 64;       // streamed vectors per LDS tile
@@ -45,7 +45,19 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
   __shared__ float ymax[YT], yinv[YT];
   __shared__ int ytgt[YT];
   __shared__ int yown[YT / 16];  // streamed queries: block b holds one whose own row is among this workgroup's stationary rows
-  __shared__ float tr[MODE == 1 ? 256 : 1][MODE == 1 ? D + 1 : 1];
+  // MODE 2 (queries stationary only) = MODE 1 plus the STREAMED side's gradient from the same weights (disc_lp.hip has the
+  // bf16 form and the reasoning): G2[y][d] = sum_x w[y,x] X[x][d] contracts over x, which sits on the lanes of the logit tile, so
+  // each wave passes its weights through a private [16 y][64 x] f32 LDS image (4 ds_write_b32 per tile, one ds_read_b128 back:
+  // lane (g, i) gets w[y = i][x = 16t + 4g .. + 3], the A operands of the 4 MFMAs of tile t); B = X[x0 + 16t + 4g + q][16dj + i].  WY[y] = sum_x w[y,x] is summed on the VALU from the same transposed registers.  Per-wave LDS slots,
+  // partial buffers and the two reduce kernels below instead of atomics.
+  constexpr bool BW = MODE >= 1, BOTH = MODE == 2;
+  constexpr int kWLd = 68;        // row stride of the weight image (floats): the 4 lane groups write different banks
+  constexpr int kDtLd = D + 4;    // row stride of a slot
+  __shared__ __attribute__((aligned(16))) float wimg[BOTH ? 4 : 1][BOTH ? 16 * kWLd : 4];
+  __shared__ float wy_lds[BOTH ? 4 : 1][BOTH ? YT : 1];
+  constexpr int kRed = !BW ? 1 : (BOTH && 4 * YT * kDtLd > 256 * (D + 1) ? 4 * YT * kDtLd : 256 * (D + 1));
+  __shared__ __attribute__((aligned(16))) float red[kRed];  // epilogue: tr[256][D + 1]; MODE 2, in the loop: 4 slots [64 y][kDtLd]
+  float (*tr)[D + 1] = (float (*)[D + 1]) red;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, i = lane & 15;
@@ -54,7 +66,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
   const int x0 = blockIdx.y * 256 + wave * 64;
   const int y_begin = blockIdx.x * a.chunk;
   const int y_end = min(a.NY, y_begin + a.chunk);
-  const float gscale = MODE == 1 ? (*a.gsc) * a.gmul : 0.f;
+  const float gscale = BW ? (*a.gsc) * a.gmul : 0.f;
 
   // ---- stationary fragments: lane (g,i) of tile t holds X[x0+16t+i][4g+16jj .. +3]
   uint4 xf[4][NJ];
@@ -83,7 +95,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
       if (ok) {
         const int64_t tg = a.idx[x] - a.row0;
         xtgt[t] = (tg >= 0 && tg < a.NY) ? (int)tg : -1;
-        if (MODE == 1) {
+        if (BW) {
           xmax[t] = a.rmax[x];
           xinv[t] = gscale / a.rsum[x];  // (the upstream scale rides on the normaliser)
         }
@@ -92,7 +104,6 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
       xtgt[t] = ok ? x : -2;  // table row index: a streamed query hits it when its target == x
     }
   }
-
   float m[4], ssum[4], wsum[4];
   f32x4 gacc[4][NJ];
 #pragma unroll
@@ -185,8 +196,26 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
       const bool whole = ybase + 16 <= y_end && x0 + 64 <= a.NX;
       const bool own_blk = !a.x_is_query && yown[yb] != 0;
       const float c2 = 2.f * a.c;
+      f32x4 oacc[BOTH ? NJ : 1];
+      float wyp = 0.f;
+      if constexpr (BOTH) {
+#pragma unroll
+        for (int dj = 0; dj < NJ; ++dj) oacc[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       auto tile = [&](int t, auto masked_c) {
         constexpr bool MASKED = decltype(masked_c)::value;
+        // MODE 2: B operands of the streamed side's product, xb[q][dj] = X[x0 + 16t + 4g + q][16dj + i], fetched per tile (L1 /
+        // L2 hits, under the logit MFMAs) rather than held: 32 more stationary registers would halve the occupancy.  Vectors
+        // past NX are clamped: their weights are zero.
+        float xb[BOTH ? 4 : 1][NJ];
+        if constexpr (BOTH) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int x = min(x0 + 16 * t + 4 * g + q, a.NX - 1);
+#pragma unroll
+            for (int dj = 0; dj < NJ; ++dj) xb[q][dj] = a.X[(int64_t)x * D + 16 * dj + i];
+          }
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
@@ -242,6 +271,20 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
               gacc[t][dj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[r], gacc[t][dj], 0, 0, 0);
             }
           }
+          if constexpr (BOTH) {
+            float* wi = wimg[wave];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wi[(4 * g + r) * kWLd + 16 * t + i] = w[r];
+            asm volatile("" ::: "memory");  // (LDS operations of one wave complete in order; only the compiler must keep it)
+            const float4 wt = *(const float4*)(wi + i * kWLd + 16 * t + 4 * g);  // w[y = i][x = 16t + 4g + q]
+            asm volatile("" ::: "memory");
+            const float wq[4] = {wt.x, wt.y, wt.z, wt.w};
+            wyp += (wq[0] + wq[1]) + (wq[2] + wq[3]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int dj = 0; dj < NJ; ++dj) oacc[dj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q], xb[q][dj], oacc[dj], 0, 0, 0);
+          }
         }
       };
 #pragma unroll
@@ -253,8 +296,28 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
         else
           tile(t, std::false_type{});
       }
+      if constexpr (BOTH) {  // lane holds out[y = 4g + r][d = 16dj + i] -> the wave's slot; wyp: the partial row sum of y = i
+        float* slot = red + wave * (YT * kDtLd);
+#pragma unroll
+        for (int dj = 0; dj < NJ; ++dj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) slot[(yb * 16 + 4 * g + r) * kDtLd + 16 * dj + i] = oacc[dj][r];
+        wyp += __shfl_xor(wyp, 16, 64);
+        wyp += __shfl_xor(wyp, 32, 64);
+        if (g == 0) wy_lds[wave][yb * 16 + i] = wyp;
+      }
     }
     __syncthreads();
+    if constexpr (BOTH) {  // the tile's four slots summed into this x-tile's slice of the partial buffers (plain stores)
+      for (int e = tid; e < YT * D; e += 256) {
+        const int row = e / D, d = e % D, o = row * kDtLd + d;
+        if (y0 + row < y_end)
+          a.G2[((int64_t)blockIdx.y * a.NY + y0 + row) * D + d] =
+              (red[o] + red[YT * kDtLd + o]) + (red[2 * YT * kDtLd + o] + red[3 * YT * kDtLd + o]);
+      }
+      if (tid < YT && y0 + tid < y_end)
+        a.WY[(int64_t)blockIdx.y * a.NY + y0 + tid] = (wy_lds[0][tid] + wy_lds[1][tid]) + (wy_lds[2][tid] + wy_lds[3][tid]);
+    }
   }
 
   if constexpr (MODE == 0) {
@@ -273,6 +336,7 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
       if (g == 0 && x < a.NX) a.part[(int64_t)blockIdx.x * a.NX + x] = make_float2(mm, ss);
     }
   } else {
+    if constexpr (BOTH) __syncthreads();  // (tr shares its memory with the slots the last tile's sums were read from)
     // grad_x = 2c (G - X W); lane holds G[x = 16t+i][d = 16dj + 4g + reg]; transpose through LDS -> row-contiguous atomics
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -294,7 +358,12 @@ __global__ __launch_bounds__(256) void disc_mfma_kernel(DiscMfmaArgs a) {
     for (int e = tid; e < 256 * D; e += 256) {
       const int rr = e / D, d = e % D;
       const int x = blockIdx.y * 256 + rr;
-      if (x < a.NX) atomicAdd(a.G + (int64_t)x * D + d, tr[rr][d]);
+      if (x < a.NX) {
+        if constexpr (BOTH)
+          a.G[((int64_t)blockIdx.x * a.NX + x) * D + d] = tr[rr][d];  // this chunk's slice of the partial buffer
+        else
+          atomicAdd(a.G + (int64_t)x * D + d, tr[rr][d]);
+      }
     }
   }
 }
@@ -385,7 +454,7 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
   a.rsum = rsum;
   a.gsc = gsc;
   a.gmul = gmul;
-  if (dq && dtable && ws && lp && D == 32 && !getenv("FHVAE_DISC_TWO_PASS")) {
+  if (dq && dtable && ws && !getenv("FHVAE_DISC_TWO_PASS")) {
     // one pass: stationary = queries, streamed = table rows; dq as in the two-pass form, dtable from the same weights
     a.X = q;
     a.Y = table;
@@ -398,7 +467,12 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
     a.G2 = a.G + nchunks * B * D;  // [nxt][S, D]
     a.WY = a.G2 + nxt * S * D;     // [nxt][S]
     dim3 grid((unsigned)nchunks, (unsigned)nxt);
-    disc_lp_launch(a, 2, grid, st);
+    if (lp && D == 32)
+      disc_lp_launch(a, 2, grid, st);
+    else if (D == 32)
+      hipLaunchKernelGGL((disc_mfma_kernel<32, 2>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((disc_mfma_kernel<16, 2>), grid, dim3(256), 0, st, a);
     int e = fh_launch_status();
     if (e) return e;
     hipLaunchKernelGGL(disc_dq_reduce_kernel, dim3((unsigned)fh_cdiv(B * D, 256)), dim3(256), 0, st, dq, a.G, (int)nchunks, B * D);
