@@ -128,6 +128,70 @@ def host_cpu_info():
             "allowed_cpus": len(allowed), "cgroup_cpu_quota": quota, "threads": n, "pin": pin[:n]}
 
 
+def hbm_record(device, B=65536, T=20, F=80, D=32, S=1000000, n_adam=64 * 1024 * 1024):
+    """Achieved HBM GB/s of the streaming kernels on the path (north_star: 'achieved HBM GB/s on the gather / NLL kernels'),
+    at sizes where a launch is bandwidth- and not latency-sized: K3 lower bound forward / backward (plain and with the bf16 pair
+    copy the per-frame head consumes), K4 mu2 gather, Adam, the loader's segment gather.  HIP events on the launch stream
+    (torch's current stream: these ops launch there), 10 launches each; bytes = ALGORITHMIC bytes (every operand once).
+    -> {name: {"us", "bytes", "gbps", "frac" (of 8 TB/s)}}"""
+    import torch
+
+    import hip_binding as hb
+
+    def t(fn, n=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    out = {}
+
+    def rec(name, sec, nbytes, note=None):
+        out[name] = {"us": sec * 1e6, "bytes": nbytes, "gbps": nbytes / sec / 1e9, "frac": nbytes / sec / 8e12}
+        if note:
+            out[name]["note"] = note
+
+    g = dict(device=device)
+    x, xm, xl = torch.randn(T, B, F, **g), torch.randn(T, B, F, **g), torch.randn(T, B, F, **g) * 0.3
+    z = [torch.randn(B, D, **g) for _ in range(5)]
+    ns = torch.randint(20, 200, (B,), **g)
+    lay = (B, T, F, (F, B * F), (F, B * F))
+    rec("elbo_fwd", t(lambda: hb.elbo(x, xm, xl, *z, ns, lay, True)), B * (3 * T * F * 4 + 6 * D * 4 + 5 * 4))
+    # backward: reads x, x_mu, x_lv and the latents, writes d_x_mu, d_x_lv and the latent gradients
+    xm2, xl2 = xm.clone().requires_grad_(True), xl.clone().requires_grad_(True)
+    zz = [v.clone().requires_grad_(True) for v in z]
+    o = hb.elbo(x, xm2, xl2, *zz, ns, lay, False)
+    go = torch.ones(B, **g)
+    rec("elbo_bwd", t(lambda: torch.autograd.grad(o[0], [xm2, xl2] + zz, go, retain_graph=True)), B * (5 * T * F * 4 + 10 * D * 4 + 4))
+    # ... with mu | logvar side by side (the per-frame head's layout): d_x_mu | d_x_lv in f32 AND once more in bf16 (+ padding)
+    pair = torch.randn(T * B, 2 * F, **g)
+    pair[:, F:] *= 0.3
+    pair.requires_grad_(True)
+    o2 = hb.elbo(x, pair[:, :F], pair[:, F:], *zz, ns, lay, False)
+    ldg = (2 * F + 63) // 64 * 64
+    rec("elbo_bwd_pair", t(lambda: torch.autograd.grad(o2[0], [pair] + zz, go, retain_graph=True)),
+        B * (5 * T * F * 4 + T * ldg * 2 + 10 * D * 4 + 4), "also timed: the slice-gradient assembly autograd adds around the kernel")
+    del o, o2, pair, xm2, xl2
+    table, idx = torch.randn(S, D, **g), torch.randint(0, S, (B,), **g)
+    rec("mu2_gather", t(lambda: hb.raw_gather_rows(table, idx)), B * (2 * D * 4 + 8), "latency-sized even at B = 65536")
+    p, gr, m, v = (torch.randn(n_adam, **g) for _ in range(4))
+    v.abs_()
+    step = torch.ones((), dtype=torch.int32, **g)
+    rec("adam", t(lambda: hb.adam_step_(p, gr, m, v, step, 1e-3, 0.95, 0.999, 1e-8)), n_adam * 28)
+    del p, gr, m, v
+    pool = torch.randn(4_000_000, F, **g)
+    st = torch.randint(0, 4_000_000 - T, (B,), **g)
+    mean, istd = torch.zeros(F, **g), torch.ones(F, **g)
+    rec("segment_gather", t(lambda: hb.segment_gather(pool, st, T, mean, istd)), 2 * B * T * F * 4)
+    return out
+
+
 def cpu_baseline(cfg, dtype, budget_s=45.0, sample_B=256):
     """the CPU oracle (oracle/ref_cpu.py, kind 'port': the reference's FHVAE is a stub; pure
     PyTorch, `torch.nn.LSTM` nets, the (B,S,D) materialisation of simple_fhvae.py:119-121) timed on ONE socket of this
@@ -287,7 +351,7 @@ def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no
 
     # The whole step (zero_grad, forward, loss, backward, Adam) is ~110 short launches: capture it once into a hipGraph and
     # replay.  The distributed runner's step contains RCCL collectives enqueued from the host between the phases: captured
-    # too when asked (--dist-graph; collectives are graph-capturable), eager otherwise.
+    # too (collectives are graph-capturable; --no-dist-graph runs it eagerly).
     use_graph = (not no_graph) and (runner is None or dist_graph)
     step = eager_step
     if use_graph:
@@ -300,12 +364,19 @@ def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no
         torch.cuda.current_stream().wait_stream(side)
         barrier()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            g_loss, g_lb = eager_step()
-
-        def step():
-            graph.replay()
-            return g_loss, g_lb
+        try:
+            with torch.cuda.graph(graph):
+                g_loss, g_lb = eager_step()
+        except Exception as exc:  # a step that cannot be captured on this stack (collectives): say so and run it eagerly
+            if runner is None:
+                raise
+            print("bench: capturing the distributed step failed (%s: %s); running it eagerly" % (type(exc).__name__, exc), file=sys.stderr)
+            use_graph = False
+            torch.cuda.synchronize()
+        if use_graph:
+            def step():
+                graph.replay()
+                return g_loss, g_lb
 
     for _ in range(warmup):
         step()
@@ -391,7 +462,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the whole step")
     ap.add_argument("--force-dist", action="store_true", help="use the distributed runner even with one rank (testing)")
-    ap.add_argument("--dist-graph", action="store_true", help="capture the distributed step (collectives included) into a hipGraph")
+    ap.add_argument("--dist-graph", action="store_true", help="(default now; kept for older command lines)")
+    ap.add_argument("--no-hbm", action="store_true", help="skip the roofline.hbm sub-record (achieved GB/s of the streaming kernels)")
+    ap.add_argument("--no-dist-graph", action="store_true",
+                    help="run the distributed step eagerly instead of replaying its captured hipGraph (collectives included)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true")
@@ -437,7 +511,7 @@ def main():
     B = args.batch or cfg["B"]
     T, F = cfg["T"], cfg["F"]
     main_res = run_gpu(cfg_name, B, dtype, args.steps, args.warmup, device, rank, world, use_dist, args.no_graph,
-                       not args.no_roofline, args.idx, args.dist_graph or (use_dist and world == 1))
+                       not args.no_roofline, args.idx, use_dist and not args.no_dist_graph)
 
     alts = []
     if default_run and world == 1 and not use_dist and not args.batch and not args.no_alt:
@@ -462,6 +536,9 @@ def main():
         for k in ("roofline", "idx"):
             if k in main_res:
                 rec[k] = main_res[k]
+        if "roofline" in rec and world == 1 and default_run and not args.no_hbm:
+            # the HBM-bound kernels of the path beside the MFMA-bound dominant one (~2 s, 5 GB of scratch tensors)
+            rec["roofline"]["hbm"] = {"peak_gbps": 8000.0, "kernels": hbm_record(device)}
         if alts:
             rec["alt"] = alts
         if not args.no_cpu_baseline and world == 1:

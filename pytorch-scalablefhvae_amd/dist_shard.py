@@ -250,7 +250,9 @@ class DistributedFHVAE:
                 self._bucket_of_ptr[v.data_ptr()] = g
             k += c
         self._pending = None  # handle of the early all-reduce over the first buckets (False: it was synchronous)
-        self.overlap = True
+        # one rank: the all-reduces move nothing, so there is nothing to hide behind the last net's weight gradients and the
+        # grouped weight-gradient launch stays whole (split in two it costs ~60 us at the bench shape)
+        self.overlap = self.sh.world > 1
 
     def _on_lstm_rec_done(self, sinks):
         """Fired by hip_binding when a net's backward RECURRENCE has been enqueued (with deferred parameter gradients: queued

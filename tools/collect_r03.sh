@@ -15,7 +15,7 @@ stats() {  # name, bench args
   rm -rf /tmp/kt_$n
   rocprofv3 --kernel-trace -d /tmp/kt_$n -o r -- python3 $R/bench.py $PROF "$@" > $O/prof_$n.log 2>&1
   db=$(find /tmp/kt_$n -name "*.db" | head -1)
-  { echo "# rocprofv3 --kernel-trace -- python3 bench.py $PROF $* (per-kernel totals via tools/rocpd_stats.py; 13 steps traced, times per step)"; python3 $R/tools/rocpd_stats.py $db 13; } > $O/${n}_kernel_stats.txt
+  { echo "# rocprofv3 --kernel-trace -- python3 bench.py $PROF $* (per-kernel totals via tools/rocpd_stats.py; 13 steps traced, times per step)"; python3 $R/tools/rocpd_stats.py $db 13 60; } > $O/${n}_kernel_stats.txt
   echo stats $n done
 }
 for w in $WHAT; do
@@ -46,9 +46,20 @@ for w in $WHAT; do
       python3 $R/tools/pmc_quick.py /tmp/pmc_fetch /tmp/pmc_write > $O/pmc_fetch_write_top.txt 2>&1 || true
       echo pmc done
       ;;
+    stream)  # achieved HBM GB/s of the streaming kernels: HIP-event table + the rocprofv3 durations of the same launches
+      rm -rf /tmp/kt_stream
+      rocprofv3 --kernel-trace -d /tmp/kt_stream -o r -- python3 $R/tools/bench_stream.py > $O/stream_events.txt 2> $O/stream.log
+      { grep -v "^W2026\|^E2026\|amdgpu.ids" $O/stream_events.txt; echo; echo "# rocprofv3 --kernel-trace -- python3 tools/bench_stream.py: average kernel durations of the same launches"; python3 $R/tools/rocpd_stats.py $(find /tmp/kt_stream -name "*.db" | head -1) 1 14; } > $O/stream_kernels_hbm.txt
+      echo stream done
+      ;;
+    dist)  # the distributed runner on one rank (captured step) beside the single-GPU step
+      python3 $R/bench.py --force-dist --no-cpu-baseline --no-alt --no-hbm > $O/bench_c3_dist_world1.json 2> $O/bench_c3_dist_world1.log
+      python3 $R/bench.py --no-cpu-baseline --no-alt --no-hbm --no-roofline > $O/bench_c3_single_ref.json 2> $O/bench_c3_single_ref.log
+      echo dist done
+      ;;
     stall)  # stall attribution of the recurrent kernels and the GEMMs around them: separate SQ / TCC passes (8 SQ slots, 4 TCC slots per pass)
       ARGS="--no-graph --no-roofline --no-cpu-baseline --no-alt --steps 6 --warmup 2"
-      K="lstm_bwd_layer_rs_kernel,lstm_fwd_cluster_kernel,lstm_fwd_wr_kernel,proj_kernel,wgrad_kernel"
+      K="lstm_bwd_layer_rs_kernel,lstm_fwd_wr_kernel,proj_kernel,wgrad_kernel,disc_lp_kernel,elbo_bwd_pair_kernel"
       rm -rf /tmp/pmc_s1 /tmp/pmc_s2 /tmp/pmc_s3 /tmp/pmc_s4
       rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_s1 -- python3 $R/bench.py $ARGS > $O/pmc_s1.log 2>&1
       rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_s2 -- python3 $R/bench.py $ARGS > $O/pmc_s2.log 2>&1
