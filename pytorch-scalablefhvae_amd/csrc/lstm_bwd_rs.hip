@@ -102,21 +102,33 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
   // epilogue operands (saved gates, c_{t-1}, the external gradient: HBM), fetched one step ahead
   uint2 gkn[RT][4];
   f32x4 cprevn[RT], extn[RT], ccurn[RT];
+  // the epilogue operands (gates, c, the external gradient) are read once and the row-major dg is written once: streaming hints,
+  // so that they do not displace the partial-dh lines the members exchange from the XCD's L2 (ClBwd::nt)
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  const bool nt = p.nt != 0;
+  auto ld16 = [&](const void* q) -> uint4 {
+    if (nt) {
+      const u32x4v v = __builtin_nontemporal_load((const u32x4v*)q);
+      return uint4{v.x, v.y, v.z, v.w};
+    }
+    return *(const uint4*)q;
+  };
+  auto ldf4 = [&](const float* q) -> f32x4 { return nt ? __builtin_nontemporal_load((const f32x4*)q) : *(const f32x4*)q; };
   auto load_epi = [&](int sn) {
     const int t = T - 1 - sn;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       if constexpr (UM) {  // unit-major (lstm_fwd_wr.hip): [unit][i,f,g,o] -> this lane's 4 units are 32 contiguous bytes
         const u16* gp = p.gates + ((int64_t)t * B + rowc[rt]) * G + uq * 4;
-        const uint4 a = *(const uint4*)gp, b = *(const uint4*)(gp + 8);
+        const uint4 a = ld16(gp), b = ld16(gp + 8);
         gkn[rt][0] = uint2{a.x, a.y}, gkn[rt][1] = uint2{a.z, a.w}, gkn[rt][2] = uint2{b.x, b.y}, gkn[rt][3] = uint2{b.z, b.w};
       } else {
         cl_load_gates(p.gates + ((int64_t)t * B + rowc[rt]) * G, uq, gkn[rt]);
       }
       if (sn == 0) ccurn[rt] = *(const f32x4*)(p.cs + ((int64_t)t * B + rowc[rt]) * H + uq);
-      cprevn[rt] = t > 0 ? *(const f32x4*)(p.cs + ((int64_t)(t - 1) * B + rowc[rt]) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      cprevn[rt] = t > 0 ? ldf4(p.cs + ((int64_t)(t - 1) * B + rowc[rt]) * H + uq) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ext_src) e = *(const f32x4*)(ext_src + ((int64_t)t * B + rowc[rt]) * H + uq);
+      if (ext_src) e = ldf4(ext_src + ((int64_t)t * B + rowc[rt]) * H + uq);
       if (sn == 0 && p.d_hn) e += *(const f32x4*)(p.d_hn + rowc[rt] * p.hn_ld + uq);
       extn[rt] = e;
     }
@@ -262,7 +274,13 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
     auto dg_store = [&](int i, const uint4& v) {
       const int c = (wave * RT * 2 + i) * 64 + lane;
       const int rw = r0 + (c >> 5), cc = c & 31;
-      if (rw < rend) *(uint4*)(p.dg + ((int64_t)t * B + rw) * G + (cc >> 3) * H + u0 + (cc & 7) * 8) = v;
+      if (rw < rend) {
+        u16* dst = p.dg + ((int64_t)t * B + rw) * G + (cc >> 3) * H + u0 + (cc & 7) * 8;
+        if (nt)
+          __builtin_nontemporal_store(u32x4v{v.x, v.y, v.z, v.w}, (u32x4v*)dst);
+        else
+          *(uint4*)dst = v;
+      }
     };
     dg_store(0, v0);
     dg_store(1, v1);

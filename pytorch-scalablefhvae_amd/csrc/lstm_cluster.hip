@@ -1467,6 +1467,7 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.xch = w.xch;
       p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
       p.tlog_slot = l == L - 1;
+      p.nt = 1;  // streaming hints on its once-read operands: HBM reads 202 -> 175 MB per launch (1.04x algorithmic), 0.5 % of a step
       p.gates_um = cluster_fwd_wr_ok(d) ? 1 : 0;  // the forward on this workspace saved the gates unit-major (same predicate)
       const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * (T - 1) * 4.0 * H);
       const int e = rs ? cluster_bwd_layer_rs(p, st) : (H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st));

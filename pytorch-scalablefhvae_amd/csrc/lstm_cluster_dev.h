@@ -169,6 +169,7 @@ struct ClBwd {
   const u16* w_above_t;  // W_ih[l+1]^T, [H,4H] bf16
   int gates_um;          // the forward saved the gates unit-major (lstm_fwd_wr.hip): [row][unit][i,f,g,o] bf16
   int tlog_slot;         // lstm_bwd_rs.hip: which half of the phase-clock log this launch writes (tools/prof_rs.py)
+  int nt;                // lstm_bwd_rs.hip: streaming (non-temporal) hints on the once-read operands and the once-written dg
 };
 
 __device__ __forceinline__ f32x4 unpack4(uint2 v) {
