@@ -996,9 +996,19 @@ extern "C" int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* bd
     }
     if (e) return e;
   }
-  for (size_t i = 0; i < fq.size(); i += kMaxGroup) {
-    const int e = launch_gemm_group(fq.data() + i, (int)std::min<size_t>(kMaxGroup, fq.size() - i), FHVAE_F32, st);
+  // one grouped launch per batch of problems with DISTINCT outputs: a net queued twice (two backward passes before one flush)
+  // accumulates into the same matrix twice, and two workgroups of one launch must not read-modify-write the same tile
+  for (size_t i = 0; i < fq.size();) {
+    size_t j = i;
+    while (j < fq.size() && j - i < (size_t)kMaxGroup) {
+      bool dup = false;
+      for (size_t k = i; k < j; ++k) dup = dup || fq[k].C == fq[j].C;
+      if (dup) break;
+      ++j;
+    }
+    const int e = launch_gemm_group(fq.data() + i, (int)(j - i), FHVAE_F32, st);
     if (e) return e;
+    i = j;
   }
   return launch_wgrad(wq.data(), (int)wq.size(), st);
 }

@@ -268,6 +268,60 @@ def test_deferred_param_grads_match_immediate(hb):
     assert (grads[0] - grads[1]).abs().max().item() <= 1e-4 * scale, ((grads[0] - grads[1]).abs().max().item(), scale)
 
 
+def test_deferred_branch_fires_the_recurrence_hook_and_accumulates_twice(hb):
+    """(a) the deferred weight-gradient branch fires hip_binding.LSTM_BWD_REC_HOOK once per net (the distributed
+    runner's overlap hangs on it); (b) two backward passes queued before ONE flush put the same weight matrix twice into one
+    grouped launch (wgrad.hip: shared_c -> atomics, no plain read-modify-write race): the flushed gradient is twice a single pass's."""
+    from fhvae import FHVAE
+    from hip_optim import FusedAdam
+    from train_model import loss_function
+
+    T, F, H, D, B, S = 20, 80, 128, 16, 128, 50
+    g = torch.Generator().manual_seed(11)
+    x, idx, ns = torch.randn(B, T, F, generator=g).cuda(), torch.randint(0, S, (B,), generator=g), torch.randint(20, 200, (B,), generator=g)
+    eps = (torch.randn(B, D, generator=g).cuda(), torch.randn(B, D, generator=g).cuda())
+    torch.manual_seed(5)
+    m = FHVAE(T * F, [H, H], [H, H], D, D, [H, H], seg_len=T, num_seqs=S, reference_compat=False, compute_dtype="bf16").cuda()
+    opt = FusedAdam(m.parameters(), lr=1e-3, betas=(0.95, 0.999))
+    fired = []
+    hb.LSTM_BWD_REC_HOOK["fn"] = lambda sinks: fired.append(len(sinks))
+    try:
+        opt.zero_grad()
+        out = m(x, idx, S, ns, eps=eps)
+        loss_function(out[0], out[1], 10.0).backward()
+        assert len(fired) == 3 and len(hb._DEFER["pending"]) == 3  # three nets, each queued behind its recurrence
+        once = opt.flat_grad().clone()
+        opt.zero_grad()
+        for _ in range(2):
+            out = m(x, idx, S, ns, eps=eps)
+            loss_function(out[0], out[1], 10.0).backward()
+        assert len(hb._DEFER["pending"]) == 6
+        twice = opt.flat_grad().clone()
+    finally:
+        hb.LSTM_BWD_REC_HOOK["fn"] = None
+    scale = once.abs().max().item()
+    assert (twice - 2 * once).abs().max().item() <= 2e-4 * scale, ((twice - 2 * once).abs().max().item(), scale)
+
+
+def test_backward_refuses_a_forward_of_another_schedule(hb):
+    """the schedule (and with it the layout of the saved gates) is re-derived from the environment per call; a switch
+    flipped between forward and backward must raise, not return gradients computed from misread gates."""
+    B, T, I, H, L = 1024, 3, 80, 256, 2
+    torch.manual_seed(2)
+    lstm = torch.nn.LSTM(I, H, L)
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    ps = [getattr(lstm, n).detach().cuda().requires_grad_(True) for n in names]
+    x = torch.randn(T, B, I).cuda()
+    hs_top, hn = hb.lstm_seq(x, None, T, ps, hb.BF16)
+    os.environ["FHVAE_NO_FWD_WR"] = "1"  # the backward would now expect row-major gates
+    try:
+        with pytest.raises(RuntimeError):
+            (hs_top.sum() + hn.sum()).backward()
+    finally:
+        os.environ.pop("FHVAE_NO_FWD_WR", None)
+        hb.flush_param_grads()
+
+
 def test_to_time_major(hb):
     x = torch.randn(6, 5, 12)
     close(hb.to_time_major(dev(x)), x.transpose(0, 1).contiguous(), rtol=0)
