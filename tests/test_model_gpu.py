@@ -150,8 +150,9 @@ def test_fhvae_bf16_tracks_f32(hb):
 
 
 @pytest.mark.parametrize("H,B,dtype,port", [(32, 48, "f32", 29617), (256, 64, "bf16", 29618), (256, 1024, "bf16", 29619)])
-def test_distributed_wrapper_world1_matches_single_gpu(hb, H, B, dtype, port):
-    """dist_shard.DistributedFHVAE on a 1-rank RCCL group (the HipBackend code path of the sharded ops):
+def test_distributed_wrapper_world1_matches_single_gpu(hb, H, B, dtype, port, monkeypatch):
+    """dist_shard.DistributedFHVAE on a 1-rank RCCL group (the HipBackend code path of the sharded ops; FHVAE_DIST_NO_SOLO=1 so
+    that the collectives are really issued to RCCL instead of being skipped as the identities they are on one rank):
     same losses as the plain single-GPU loop over several Adam steps.  The bf16 cases run the persistent LSTM kernels
     (contraction-split and rows form): there the runner reduces the first two gradient buckets from its hook between a
     net's recurrence and its parameter gradients."""
@@ -183,11 +184,16 @@ def test_distributed_wrapper_world1_matches_single_gpu(hb, H, B, dtype, port):
         opt.step()
         ref_losses.append(loss.item())
 
+    if port % 2:  # odd ports: real RCCL calls; even: the skipping default
+        monkeypatch.setenv("FHVAE_DIST_NO_SOLO", "1")
+    else:
+        monkeypatch.delenv("FHVAE_DIST_NO_SOLO", raising=False)
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
         m2 = build()
         runner = DistributedFHVAE(m2, lr=1e-3, betas=(0.95, 0.999))
+        assert runner.sh.solo == (not port % 2)
         fwd = m2.forward
         m2.forward = lambda *a, **k: fwd(*a, eps=eps, **k)  # same draws as the reference loop
         got = [runner.train_step(x, idx, ns, alpha=10.0)[0].item() for _ in range(3)]
