@@ -7,10 +7,10 @@
 // PRODUCES dg_t for the 256 gate columns {g*H + 64m + j}.  lstm_bwd_layer_ks_kernel (round 2) made every member read the
 // cluster's whole dg_t (64 KB per CU and step) before it could multiply.  Here a member multiplies the K-slice it already holds
 // -- its own 256 gate columns, straight out of its epilogue -- by its rows of W_hh for ALL 256 units, and hands each other
-// member the (32 rows x 64 units) f32 partial of that member's units: 24 KB out and 24 KB in per CU and step, six 16-byte loads
-// per lane instead of sixteen, no K-split reduction through LDS, and the weights (32 fragments per wave) stay in registers:
+// member the (32 rows x 64 units) partial of that member's units (bf16): 12 KB out and 12 KB in per CU and step, six 8-byte loads
+// per lane instead of sixteen 16-byte ones, no K-split reduction through LDS, and the weights (32 fragments per wave) stay in registers:
 //   wave w multiplies unit tile w (16 units) of every destination member: its own-destination tile is already in the epilogue's
-//   lane layout (unit quad on lane>>4, row on lane&15), the three others leave as whole 1-KB fragments that the destination's
+//   lane layout (unit quad on lane>>4, row on lane&15), the three others leave as whole 512-byte fragments that the destination's
 //   wave w adds to its accumulator as they are.
 // Per step (t = T-1-s):  wait for the flags -> 6 partial loads -> dh = external + from-above + own + 3 partials -> elementwise
 // LSTM backward -> dg_t (bf16) into a 16-KB LDS image [row][gate][64 units] -> barrier -> 16 B-fragment reads + 64 MFMAs per wave
@@ -36,10 +36,12 @@ namespace {
 constexpr int kH = 256, kG = 4 * kH, kHU = 64, kNU = 4;
 constexpr int kKS = 8;     // k-steps (32 gate columns) of a member's own 256 gate columns
 
-// byte offset of the 1-KB fragment (parity, cluster, source member, slot j = (dst - src) & 3 in 1..3, wave, row tile)
+// byte offset of the 512-byte fragment (parity, cluster, source member, slot j = (dst - src) & 3 in 1..3, wave, row tile): the
+// partials travel in bf16 (8 bytes per lane: 4 units of one row) -- half the bytes through the L2 and to memory (VERDICT r02 #1:
+// the f32 partials were 126 MB of the launch's 207 MB of HBM writes), one more rounding on three of the four terms of dh
 template <int RT>
 __device__ __forceinline__ int rs_xoff(int par, int cluster, int src, int j, int wave, int rt) {
-  return ((((((par * 64 + cluster) * kNU + src) * 3 + (j - 1)) * 4 + wave) * RT + rt) << 10);
+  return ((((((par * 64 + cluster) * kNU + src) * 3 + (j - 1)) * 4 + wave) * RT + rt) << 9);
 }
 
 template <int RT>
@@ -153,15 +155,17 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
     f32x4 dh[RT];
     CL_TLOG(s * 8 + 1);
     // ---- the other members' partials of dh_t (published as epoch s)
-    uint4 pin[RT][3];
+    uint2 pin[RT][3];
     if (s > 0) {
       if (!cluster_wait(p.sync, flags, kNU, ep0 + (unsigned)s)) return;
       CL_TLOG(s * 8 + 2);
 #pragma unroll
       for (int jj = 1; jj < kNU; ++jj)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          pin[rt][jj - 1] = load_sc1(x_rs, rs_xoff<RT>((s - 1) & 1, cluster, (me - jj) & 3, jj, wave, rt) + lane * 16);
+        for (int rt = 0; rt < RT; ++rt) {
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(x_rs, rs_xoff<RT>((s - 1) & 1, cluster, (me - jj) & 3, jj, wave, rt) + lane * 8, 0, kSc1);
+          pin[rt][jj - 1] = uint2{v.x, v.y};
+        }
     }
     uint2 gk[RT][4];
     f32x4 cprev[RT];
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dh[rt] += __builtin_bit_cast(f32x4, pin[rt][j]);
+        for (int j = 0; j < 3; ++j) dh[rt] += unpack4(pin[rt][j]);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (s + 1 < T) load_epi(s + 1);  // behind the partial loads: lands under the epilogue and the MFMAs
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
         own[rt] = acc[rt][0];
 #pragma unroll
         for (int j = 1; j < kNU; ++j)
-          *(f32x4*)((char*)p.xch + rs_xoff<RT>(s & 1, cluster, me, j, wave, rt) + lane * 16) = acc[rt][j];  // what the members wait for
+          *(uint2*)((char*)p.xch + rs_xoff<RT>(s & 1, cluster, me, j, wave, rt) + lane * 8) = pack4(acc[rt][j]);  // what the members wait for
       }
     }
     // the row-major copy of dg_t (what the weight-gradient contractions and the layer below read): whole 128-byte lines out of

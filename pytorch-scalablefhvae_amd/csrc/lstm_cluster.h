@@ -19,8 +19,8 @@ constexpr int kSyncWordsUsed = 3072;  // the words the operand cast re-arms: the
 constexpr int kSeqEpochs = 4096;
 
 // bf16 elements of the exchange buffer the partial-dh backward (lstm_bwd_rs.hip) needs: 2 parities x 64 clusters x 4 sources x
-// 3 destinations x 4 waves x 2 row tiles x 1 KB
-constexpr int64_t kRsXchElems = 2LL * 64 * 4 * 3 * 4 * 2 * 512;
+// 3 destinations x 4 waves x 2 row tiles x 512 B (bf16 partials)
+constexpr int64_t kRsXchElems = 2LL * 64 * 4 * 3 * 4 * 2 * 256;
 
 struct ClusterWeights {  // bf16 operand copies in the workspace
   const u16* w_ih[FHVAE_MAX_LAYERS];    // [4H, H]   (l >= 1)

@@ -118,6 +118,7 @@ __device__ __forceinline__ void cl_store_gates(u16* row_base, int uq, const uint
 
 // L1-bypassing 16-byte loads of exchanged data into registers (the compiler tracks their vmcnt)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
