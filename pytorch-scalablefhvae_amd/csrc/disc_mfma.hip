@@ -480,7 +480,9 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
                        2.f * c, S, (int)D);
     return fh_launch_status();
   }
-  if (dq) {  // stationary = queries, streamed = table rows
+  if (dq) {  // stationary = queries, streamed = table rows; the workgroups ADD their partial gradients: zero first
+    hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
+    if (he != hipSuccess) return (int)he;
     a.X = q;
     a.Y = table;
     a.NX = (int)B;

@@ -962,10 +962,6 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
   FH_CHECK_I32(S);
   hipStream_t st = (hipStream_t)stream;
   if (disc_mfma_supported(B, S, D) && !getenv("FHVAE_DISC_VALU")) {
-    if (dq) {
-      hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);
-      if (he != hipSuccess) return (int)he;
-    }
     int e = disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, (float*)ws, B, S, D,
                           dtype == FHVAE_BF16, st);
     if (e) return e;
