@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 8
+#define FHVAE_ABI_VERSION 9
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -235,6 +235,10 @@ int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* descs, int n,
  * FHVAE_ERR_ALIGN when the preconditions do not hold. */
 int fhvae_wgrad_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc, int64_t M,
                      int64_t N, int64_t K, void* stream);
+/* The same contraction with f32 operands on exact-f32 MFMA (the parity mode's weight gradients; lda, ldb multiples of 4,
+ * K*ld*4 < 2^31). */
+int fhvae_wgrad_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t M, int64_t N,
+                    int64_t K, void* stream);
 
 /* c[M,N] (f32, ldc) = a[M,K] . b[N,K]^T (+ bias[N], may be NULL): bf16 operands with the contraction index CONTIGUOUS in both
  * (lda, ldb in elements, multiples of 8; K % 64 == 0, N % 4 == 0; 16-byte aligned bases; M*lda*2 < 2^31) -- an activation matrix

@@ -17,6 +17,7 @@
 #include "lstm_cell.h"
 #include "lstm_cluster.h"
 #include "wgrad.h"
+#include "wgrad_f32.h"
 #include <algorithm>
 #include <vector>
 #include "trace.h"
@@ -811,7 +812,7 @@ constexpr int64_t kWgradMinK = 1024;  // shorter contractions stay on the generi
 // caller launches everything it has collected (possibly from several nets) as one grouped launch (launch_wgrad).
 template <typename T>
 static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hipStream_t st, std::vector<WgProblem>* wq = nullptr,
-                            std::vector<GemmParams>* fq = nullptr) {
+                            std::vector<GemmParams>* fq = nullptr, std::vector<WgProblem32>* wq32 = nullptr) {
   const fhvae_lstm_desc* d = &bd->f;
   const int64_t B = d->B, T_ = d->T, I = d->I, Ic = d->Ic, H = d->H;
   const int L = d->L;
@@ -824,6 +825,16 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
   int ng = 0;
   // -> true: taken by the dedicated long-K kernel (queued in wq)
   auto wgrad_long = [&](const void* a, int64_t lda, const void* b, int64_t ldb, int64_t Kc, float* c, int64_t ldc, int64_t Ncols) {
+    if (sizeof(T) == 4) {  // f32 mode: the exact-f32 form of the long-K kernel (wgrad_f32.hip)
+      if (!wq32 || Kc < kWgradMinK) return false;
+      WgProblem32 w = {};
+      w.A = (const float*)a, w.B = (const float*)b, w.C = c;
+      w.lda = lda, w.ldb = ldb, w.ldc = ldc;
+      w.M = (int)G, w.N = (int)Ncols, w.K = (int)Kc;
+      if (!wgrad32_eligible(w)) return false;
+      wq32->push_back(w);
+      return true;
+    }
     if (!wq || sizeof(T) != 2 || Kc < kWgradMinK) return false;
     WgProblem w = {};
     w.A = (const u16*)a, w.B = (const u16*)b, w.C = c;
@@ -931,7 +942,11 @@ extern "C" int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* bd, void* stream) {
       e = lstm_dxc(bd, st);
       if (e) return e;
     }
-    return par ? lstm_param_grads<float>(bd, op, st) : FHVAE_OK;
+    if (!par) return FHVAE_OK;
+    std::vector<WgProblem32> wq32;
+    e = lstm_param_grads<float>(bd, op, st, nullptr, nullptr, getenv("FHVAE_NO_WGRAD") ? nullptr : &wq32);
+    if (e) return e;
+    return launch_wgrad32(wq32.data(), (int)wq32.size(), st);
   }
   Ops<u16> op = ops_bf16(d);  // filled by the forward
   if (rec) {
@@ -980,6 +995,7 @@ extern "C" int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* bd
     wq.push_back(p);
   }
   std::vector<GemmParams> fq;  // the f32 (B-row) contractions of the time-constant inputs
+  std::vector<WgProblem32> wq32;  // f32 mode: the long contractions of every queued net, one grouped launch (wgrad_f32.hip)
   const bool use_wq = !getenv("FHVAE_NO_WGRAD");
   for (int i = 0; i < n; ++i) {
     const fhvae_lstm_bwd_desc* bd = bds[i];
@@ -990,7 +1006,7 @@ extern "C" int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* bd
     FH_CHECK_PTR(bd->dgates);
     if (d->Ic > 0) FH_CHECK_PTR(bd->dgsum);
     if (d->dtype == FHVAE_F32) {
-      e = lstm_param_grads<float>(bd, ops_f32(d), st);
+      e = lstm_param_grads<float>(bd, ops_f32(d), st, nullptr, nullptr, use_wq ? &wq32 : nullptr);
     } else {
       e = lstm_param_grads<u16>(bd, ops_bf16(d), st, use_wq ? &wq : nullptr, &fq);
     }
@@ -1009,6 +1025,10 @@ extern "C" int fhvae_lstm_param_grads_multi(const fhvae_lstm_bwd_desc* const* bd
     const int e = launch_gemm_group(fq.data() + i, (int)(j - i), FHVAE_F32, st);
     if (e) return e;
     i = j;
+  }
+  {
+    const int e = launch_wgrad32(wq32.data(), (int)wq32.size(), st);
+    if (e) return e;
   }
   return launch_wgrad(wq.data(), (int)wq.size(), st);
 }

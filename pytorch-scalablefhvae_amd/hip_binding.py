@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
 
 F32, BF16 = 0, 1
 MAX_LAYERS = 4
-ABI_VERSION = 8  # FHVAE_ABI_VERSION of include/fhvae_hip.h
+ABI_VERSION = 9  # FHVAE_ABI_VERSION of include/fhvae_hip.h
 #: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
 INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
@@ -106,6 +106,7 @@ SIGNATURES = {
     "fhvae_lstm_param_grads_multi": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp]),
     "fhvae_wgrad_desc_ok": (C.c_int, [_vp]),
     "fhvae_wgrad_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "fhvae_wgrad_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
     "fhvae_proj_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "fhvae_mu2_gather_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     "fhvae_mu2_gather_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp]),
@@ -1092,6 +1093,19 @@ def wgrad_bf16_(c, a, b):
     N = b.shape[1]
     with _Timed("fhvae_wgrad_bf16"):
         _check(lib.fhvae_wgrad_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), M, N, K, _stream()), "fhvae_wgrad_bf16")
+    return c
+
+
+def wgrad_f32_(c, a, b):
+    """c[M,N] (f32) += a[K,M]^T . b[K,N] for f32 a, b whose rows are the contraction index (fhvae_wgrad_f32: exact-f32 MFMA)."""
+    lib = load_library()
+    _need_gpu(c, a, b)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and c.dtype == torch.float32
+    assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1 and a.shape[0] == b.shape[0]
+    K, M = a.shape
+    N = b.shape[1]
+    with _Timed("fhvae_wgrad_f32"):
+        _check(lib.fhvae_wgrad_f32(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), M, N, K, _stream()), "fhvae_wgrad_f32")
     return c
 
 

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), "libfhvae_hip.so lacks %s" % n
         assert n in hb.SIGNATURES, "hip_binding does not bind %s" % n
     assert set(hb.SIGNATURES) == set(names)
-    assert lib.fhvae_abi_version() == 8
+    assert lib.fhvae_abi_version() == 9
     assert lib.fhvae_strerror(-1) == b"required pointer is NULL"
 
 

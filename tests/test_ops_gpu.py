@@ -213,6 +213,28 @@ def test_wgrad_bf16_vs_cpu_matmul(hb, K, M, N):
     assert (cd.cpu().double() - want2).abs().max().item() <= 4e-5 * K ** 0.5 + 1e-6
 
 
+@pytest.mark.parametrize("K,M,N", [(20480, 1024, 256), (1280, 512, 80), (5000, 192, 112), (777, 1024, 256), (4096, 2048, 512),
+                                   (32, 256, 256), (4096 + 4, 320, 136)])
+def test_wgrad_f32_vs_cpu_matmul(hb, K, M, N):
+    """fhvae_wgrad_f32: the exact-f32 form of the long-K weight-gradient kernel (csrc/wgrad_f32.hip: 256x256 / 256x128 tiles, LDS-DMA
+    double buffer, one ds_read_b32 per operand scalar, split-K atomics), K tails / ragged M, N / odd slice counts included, against the
+    f64 CPU matmul of the same f32 operands.  Exact-f32 products; what remains is the f32 accumulation (a random walk of K
+    roundings at the partial sum's magnitude): 1e-5 of the output's scale sqrt(K), the bound of the bf16 kernel's test."""
+    torch.manual_seed(K + M)
+    lda, ldb = M + (4 if K % 2 else 0), N + (8 if M % 3 == 0 else 0)
+    a_full, b_full = torch.randn(K, lda), torch.randn(K, ldb)
+    a, b = a_full[:, :M], b_full[:, :N]
+    c0 = torch.randn(M, N)
+    want = c0.double() + a.double().t() @ b.double()
+    cd = dev(c0)
+    hb.wgrad_f32_(cd, dev(a_full)[:, :M], dev(b_full)[:, :N])
+    err = (cd.cpu().double() - want).abs().max().item()
+    assert err <= 1e-5 * K ** 0.5 + 1e-6, (err, K)
+    hb.wgrad_f32_(cd, dev(a_full)[:, :M], dev(b_full)[:, :N])  # accumulates
+    want2 = want + a.double().t() @ b.double()
+    assert (cd.cpu().double() - want2).abs().max().item() <= 2e-5 * K ** 0.5 + 1e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(40960, 256, 1024), (40960, 160, 256), (2048, 64, 512), (1000, 256, 64), (300, 96, 128), (17, 4, 64),
                                    (5000, 512, 320)])
 def test_proj_bf16_vs_cpu_matmul(hb, M, N, K):
