@@ -202,20 +202,8 @@ __global__ __launch_bounds__(256, 2) void disc_mfma_kernel(DiscMfmaArgs a) {
 #pragma unroll
         for (int dj = 0; dj < NJ; ++dj) oacc[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      auto tile = [&](int t, auto masked_c) {
-        constexpr bool MASKED = decltype(masked_c)::value;
-        // MODE 2: B operands of the streamed side's product, xb[q][dj] = X[x0 + 16t + 4g + q][16dj + i], fetched per tile (L1 /
-        // L2 hits, under the logit MFMAs) rather than held: 32 more stationary registers would halve the occupancy.  Vectors
-        // past NX are clamped: their weights are zero.
-        float xb[BOTH ? 4 : 1][NJ];
-        if constexpr (BOTH) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int x = min(x0 + 16 * t + 4 * g + q, a.NX - 1);
-#pragma unroll
-            for (int dj = 0; dj < NJ; ++dj) xb[q][dj] = a.X[(int64_t)x * D + 16 * dj + i];
-          }
-        }
+      // the logit product of tile t: 8 dependent MFMAs
+      auto logits = [&](int t) __attribute__((always_inline)) -> f32x4 {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
@@ -225,6 +213,13 @@ __global__ __launch_bounds__(256, 2) void disc_mfma_kernel(DiscMfmaArgs a) {
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua.z), __uint_as_float(ub.z), acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua.w), __uint_as_float(ub.w), acc, 0, 0, 0);
         }
+        return acc;
+      };
+      auto tile = [&](int t, auto masked_c, const f32x4& acc) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_c)::value;
+        // MODE 2: B operands of the streamed side's product, xb[q][dj] = X[x0 + 16t + 4g + q][16dj + i], fetched per tile (L1 /
+        // L2 hits) rather than held: 32 more stationary registers would halve the occupancy.  Vectors past NX are clamped: their
+        // weights are zero.
         const bool xok = x0 + t * 16 + i < a.NX;
         const float cxn = a.c * xn[t];
         float lg[4];
@@ -261,6 +256,15 @@ __global__ __launch_bounds__(256, 2) void disc_mfma_kernel(DiscMfmaArgs a) {
             w[r] = (!MASKED || lg[r] > -INFINITY) ? p : 0.f;  // (own pairs: masked above, added by disc_own_bwd_kernel)
             wsum[t] += w[r];
           }
+          float xb[BOTH ? 4 : 1][NJ];  // MODE 2: requested behind the exp arithmetic; their latency hides under the G product's MFMAs
+          if constexpr (BOTH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int x = min(x0 + 16 * t + 4 * g + q, a.NX - 1);
+#pragma unroll
+              for (int dj = 0; dj < NJ; ++dj) xb[q][dj] = a.X[(int64_t)x * D + 16 * dj + i];
+            }
+          }
           // G^T[d][x] += sum_y Y[y][d] * w[y][x]: A = Y^T from LDS (lane: d = 16*dj + i, y = 4g + r), B = w[r]
 #pragma unroll
           for (int dj = 0; dj < NJ; ++dj) {
@@ -287,14 +291,33 @@ __global__ __launch_bounds__(256, 2) void disc_mfma_kernel(DiscMfmaArgs a) {
           }
         }
       };
+      // Interior blocks with no masked tile (all but a few per cent): ONE basic block for the four tiles, tile t + 1's logit MFMAs
+      // issued before tile t's exp / weight arithmetic, so that the matrix pipe works under the VALU of the same wave (with a
+      // branch per tile the chains ran one after the other: MfmaUtil 46 % forward; S = 1M forward 1.81 -> 1.65 ms).
+      bool any_masked = !whole || own_blk;
+      if (a.x_is_query) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        bool masked = !whole || own_blk;
-        if (a.x_is_query) masked = masked || __any((unsigned)(xtgt[t] - ybase) < 16u);
-        if (masked)
-          tile(t, std::true_type{});
-        else
-          tile(t, std::false_type{});
+        for (int t = 0; t < 4; ++t) any_masked = any_masked || __any((unsigned)(xtgt[t] - ybase) < 16u);
+      }
+      if (!BOTH && !any_masked) {  // (the one-pass backward has no registers for a second accumulator in flight: 101 spills)
+        f32x4 nxt = logits(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 cur = nxt;
+          if (t + 1 < 4) nxt = logits(t + 1);
+          tile(t, std::false_type{}, cur);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          bool masked = !whole || own_blk;
+          if (a.x_is_query) masked = masked || __any((unsigned)(xtgt[t] - ybase) < 16u);
+          const f32x4 acc = logits(t);
+          if (masked)
+            tile(t, std::true_type{}, acc);
+          else
+            tile(t, std::false_type{}, acc);
+        }
       }
       if constexpr (BOTH) {  // lane holds out[y = 4g + r][d = 16dj + i] -> the wave's slot; wyp: the partial row sum of y = i
         float* slot = red + wave * (YT * kDtLd);
