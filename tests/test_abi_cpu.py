@@ -61,6 +61,21 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     d = hb.LstmDesc()
     d.L = 9
     assert lib.fhvae_lstm_seq_fwd(ctypes.byref(d), None) == -2
+    # round-3 entries: NULL operands, a contraction length the projection kernel does not take, unaligned leading dimensions,
+    # a stacked-weight buffer narrower than 2D, a wgrad descriptor that is not eligible
+    assert lib.fhvae_proj_bf16(None, 64, None, 64, None, None, 64, 8, 8, 64, None) == -1
+    buf = (ctypes.c_float * 4096)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.fhvae_proj_bf16(p, 72, p, 72, None, p, 8, 8, 8, 72, None) == -4          # K = 72 is not a multiple of 64
+    assert lib.fhvae_wgrad_f32(None, 4, None, 4, None, 4, 4, 4, 4, None) == -1
+    assert lib.fhvae_wgrad_f32(p, 6, p, 8, p, 8, 4, 8, 16, None) == -4                   # lda = 6 is not a multiple of 4
+    assert lib.fhvae_head_pair_weights(p, p, p, p, 8, 8, 16, None) == -2                 # ldt = 8 < 2D = 16
+    assert lib.fhvae_gauss_head_bwd_pair(None, 64, None, 64, None, 64, None, 0, None, 64, None, None, None, None, 8, 64, 8, None) == -1
+    assert lib.fhvae_gauss_reparam_bwd_pair(None, None, p, None, None, 8, p, 16, 4, 8, None) == -1   # d_sample without eps / logvar
+    w = hb.WgradDesc(None, 8, 0, None, 8, None, 8, 8, 8, 64)
+    assert lib.fhvae_wgrad_desc_ok(ctypes.byref(w)) == 0
+    assert lib.fhvae_disc_lse_bwd_ws_bytes(2048, 28000, 32) > 0 and lib.fhvae_disc_lse_bwd_ws_bytes(8, 8, 32) == 0
+    assert lib.fhvae_elbo_colsum_rows(2048) == 1024
 
 
 def test_drop_in_surface_and_no_cpu_fallback(lib):
