@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libfhvae_hip.so")
-SOURCES = ["gemm.hip", "lstm.hip", "lstm_cluster.hip", "lstm_bwd_rs.hip", "lstm_bwd_rs2.hip", "lstm_fwd_wr.hip", "proj.hip", "loss.hip", "disc_mfma.hip", "data.hip", "trace.hip", "wgrad.hip", "wgrad_f32.hip", "disc_lp.hip", "lstm_cell.hip"]
+SOURCES = ["gemm.hip", "lstm.hip", "lstm_cluster.hip", "lstm_bwd_rs.hip", "lstm_fwd_wr.hip", "proj.hip", "loss.hip", "disc_mfma.hip", "data.hip", "trace.hip", "wgrad.hip", "wgrad_f32.hip", "disc_lp.hip", "lstm_cell.hip"]
 # -amdgpu-mfma-vgpr-form: MFMA results stay in VGPRs.  By default the backend puts accumulators in AGPRs and copies them
 # around every non-MFMA use (v_accvgpr_read/write, 4 issue cycles each): 288 such moves in the long-K GEMM's loop, none with
 # this form; measured 791 -> 810 k segments/s at B=2048, 275 -> 284 k at B=256.

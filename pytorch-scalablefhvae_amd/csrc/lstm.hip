@@ -369,7 +369,6 @@ static LpLayout lp_layout(const fhvae_lstm_desc* d) {
      // the per-layer backward at H = 256 (lstm_bwd_rs.hip: a fixed kRsXchElems whatever the batch)
     int64_t cnt = 2 * (int64_t)d->L * d->B * 4 * d->H;
     if (d->H == 256 && cnt < fh::kRsXchElems) cnt = fh::kRsXchElems;
-    if (d->H == 256 && d->L == 2 && cnt < fh::kRs2XchElems) cnt = fh::kRs2XchElems;  // both layers in one launch (lstm_bwd_rs2.hip)
     o.xch = take(cnt);
   }
   o.total = n;

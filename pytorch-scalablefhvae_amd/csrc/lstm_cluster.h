@@ -21,9 +21,6 @@ constexpr int kSeqEpochs = 4096;
 // bf16 elements of the exchange buffer the partial-dh backward (lstm_bwd_rs.hip) needs: 2 parities x 64 clusters x 4 sources x
 // 3 destinations x 4 waves x 2 row tiles x 512 B (bf16 partials)
 constexpr int64_t kRsXchElems = 2LL * 64 * 4 * 3 * 4 * 2 * 256;
-// ... and the two-layer launch (lstm_bwd_rs2.hip): recurrent partials 2 parities x 32 super-clusters x 2 layers x 4 sources x 3
-// destinations x 4 waves x 4 row tiles x 512 B, from-above partials 3 ring slots x 32 x 4 sources x 4 destinations x 4 x 4 x 512 B
-constexpr int64_t kRs2XchElems = (2LL * 32 * 2 * 4 * 3 * 4 * 4 * 512 + 3LL * 32 * 4 * 4 * 4 * 4 * 512) / 2;
 
 struct ClusterWeights {  // bf16 operand copies in the workspace
   const u16* w_ih[FHVAE_MAX_LAYERS];    // [4H, H]   (l >= 1)

@@ -1413,50 +1413,6 @@ static bool cluster_bwd_rs(const fhvae_lstm_desc* d) {
   return cluster_eligible(d) && cluster_form(d) == 1 && d->H == 256 && !getenv("FHVAE_NO_RS");
 }
 
-// ... and a two-layer net runs both layers in ONE launch, the lower layer a step behind the top one (lstm_bwd_rs2.hip)
-static bool cluster_bwd_pair(const fhvae_lstm_desc* d) { return cluster_bwd_rs(d) && d->L == 2 && !getenv("FHVAE_NO_RS_PAIR"); }
-
-static int cluster_bwd_pair_launches(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
-  const fhvae_lstm_desc* d = &bd->f;
-  const int64_t B = d->B, T = d->T, H = d->H;
-  constexpr int NC = 32;  // super-clusters of 8 workgroups
-  const int64_t chunk = (int64_t)NC * 64;
-  for (int64_t row0 = 0; row0 < B; row0 += chunk) {
-    const int64_t nrows = B - row0 < chunk ? B - row0 : chunk;
-    ClBwd p = {};
-    int RB;
-    cluster_rows(nrows, NC, &p.Mc, &RB);
-    p.B = (int)B;
-    p.T = (int)T;
-    p.NU = 4;
-    p.row0 = (int)row0;
-    p.nrows = (int)nrows;
-    for (int l = 0; l < 2; ++l) {
-      p.w_ih_t[l] = w.w_ih_t[l];
-      p.w_hh_t[l] = w.w_hh_t[l];
-      p.db_ih[l] = bd->db_ih[l];
-      p.db_hh[l] = bd->db_hh[l];
-    }
-    p.gates = (const u16*)d->gates;
-    p.cs = d->cs;
-    p.d_hs_top = bd->d_hs_top;
-    p.d_hn = bd->d_hn;
-    p.hn_ld = 2 * (int)H;
-    p.dg = (u16*)bd->dgates;
-    p.dgsum = d->Ic > 0 ? bd->dgsum : nullptr;
-    p.sync = (unsigned*)d->lp;
-    p.xch = w.xch;
-    p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
-    p.nt = 1;
-    p.gates_um = cluster_fwd_wr_ok(d) ? 1 : 0;
-    const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * (T + 2.0 * (T - 1)) * 4.0 * H);
-    const int e = cluster_bwd_pair_rs(p, st);
-    trace_end(st, ts);
-    if (e) return e;
-  }
-  return FHVAE_OK;
-}
-
 // rows form, layer by layer: the top layer's recurrence as one persistent launch, then for every layer below the from-above term
 // dg^{l+1} . W_ih[l+1] of ALL steps as one GEMM into bd->ws_below (it is not recurrent), then that layer's launch with it as the
 // external gradient.  H = 256: 64 units per member, partial-dh exchange (lstm_bwd_rs.hip, 2048 rows per launch, larger batches
@@ -1465,7 +1421,6 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
   const fhvae_lstm_desc* d = &bd->f;
   const int H = (int)d->H, L = d->L;
   const bool rs = cluster_bwd_rs(d);
-  if (cluster_bwd_pair(d)) return cluster_bwd_pair_launches(bd, w, st);
   const int HU = rs ? 64 : 32;
   const int NU = H / HU, NC = kGrid / NU;
   const int64_t B = d->B, T = d->T, G = 4 * H;
@@ -1525,7 +1480,7 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
 
 // the layer-by-layer backward (rows form, two layers or more) hands the from-above gradient to the lower layer through
 // bd->ws_below (T,B,H) f32
-bool cluster_needs_ws_below(const fhvae_lstm_desc* d) { return cluster_eligible(d) && cluster_form(d) == 1 && d->L >= 2 && !cluster_bwd_pair(d); }
+bool cluster_needs_ws_below(const fhvae_lstm_desc* d) { return cluster_eligible(d) && cluster_form(d) == 1 && d->L >= 2; }
 
 int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st) {
   const fhvae_lstm_desc* d = &bd->f;

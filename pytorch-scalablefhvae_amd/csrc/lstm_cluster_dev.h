@@ -216,8 +216,4 @@ int cluster_fwd_wr(const ClFwd& p, hipStream_t st);
 // lstm_bwd_rs.hip: backward of ONE layer, H = 256, partial-dh exchange (p.NU = 4, p.Mc <= 32); p.xch holds kRsXchElems bf16 elements
 int cluster_bwd_layer_rs(const ClBwd& p, hipStream_t st);
 
-// lstm_bwd_rs2.hip: backward of BOTH layers of a two-layer H = 256 net in one launch (p.NU = 4, p.Mc <= 64; all-layer pointers as
-// in the wavefront kernels: gates / cs / dg of layer l at + l * T * B * ., d_hn unsliced); p.xch holds kRs2XchElems bf16 elements
-int cluster_bwd_pair_rs(const ClBwd& p, hipStream_t st);
-
 }  // namespace fh

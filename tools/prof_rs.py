@@ -1,5 +1,4 @@
-"""Phase clocks of the partial-dh backward -- both layers in one launch (csrc/lstm_bwd_rs2.hip; default) or a launch per layer
-(csrc/lstm_bwd_rs.hip; FHVAE_NO_RS_PAIR=1) --, cluster 0 / member 0: FHVAE_CLUSTER_TLOG=1 makes
+"""Phase clocks of the partial-dh per-layer backward (csrc/lstm_bwd_rs.hip), cluster 0 / member 0: FHVAE_CLUSTER_TLOG=1 makes
 the kernel log wall_clock64() (100 MHz) per step at: 0 step begins, 2 flags seen, 3 partials added + epilogue + image barrier,
 4 MFMAs + partial stores issued, 5 published.  The lower layer's launch logs at slot 0, the top layer's at slot 256."""
 import os, sys
