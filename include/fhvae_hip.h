@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 9
+#define FHVAE_ABI_VERSION 10
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -92,10 +92,11 @@ int fhvae_gauss_reparam_pair_fwd(const float* out, int64_t ldo, const float* eps
                                  int64_t M, int64_t D, void* stream);
 /* g_lp[m, 0..D) = bf16(d_mu + d_sample), [D..2D) = bf16(d_logvar + d_sample * eps * 0.5 * exp(0.5 logvar)), [2D..ldg) = 0:
  * the upstream gradient of both linear layers of a head as one bf16 operand (any of d_mu / d_logvar / d_sample may be NULL;
- * d_sample needs eps and logvar; logvar has row stride ld_lv). */
+ * d_sample needs eps and logvar; logvar has row stride ld_lv).  db_mu / db_lv [D] (may be NULL): the bias gradients, += the
+ * column sums of the two halves of g_lp (nn.Linear's bias backward) from the same launch where a workgroup covers whole rows. */
 int fhvae_gauss_reparam_bwd_pair(const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
-                                 const float* logvar, int64_t ld_lv, void* g_lp, int64_t ldg, int64_t M, int64_t D,
-                                 void* stream);
+                                 const float* logvar, int64_t ld_lv, void* g_lp, int64_t ldg, float* db_mu, float* db_lv,
+                                 int64_t M, int64_t D, void* stream);
 /* Backward of both linear layers of a head (nn.Linear backward at simple_fhvae.py:197-198,:210-211) from the bf16 operand
  * g_lp [M,ldg] (fhvae_gauss_reparam_bwd_pair or fhvae_elbo_bwd's d_x_pair_lp): dh[M,K] = g . [W_mu; W_lv] (OVERWRITTEN, may be
  * NULL), dw_mu / dw_lv [D,K] += g^T . h_lp (skipped when both are NULL), db_mu / db_lv [D] += column sums of g (the sum of the
@@ -163,6 +164,19 @@ typedef struct fhvae_lstm_desc {
                     copies of x, xc, the weights and the transposed weights, the backward reuses it.  It also
                     holds the persistent schedules' sync block (first FHVAE_LSTM_SYNC_BYTES) and their exchange
                     buffer (2*L*B*4H bf16): keep it alive and untouched between the forward and its backward */
+  void* hn_lp;   /* BF16 mode, optional (may be NULL): (B, L*H) bf16 copy of hn -- the operand of a bf16 Gaussian head
+                    (simple_fhvae.py:193-216) straight from the kernel that produced the final states, instead of a cast launch
+                    per head and step.  Always filled when set (the schedules without the fused store cast hn at the end). */
+  /* BF16 mode, optional (head_w_mu == NULL: none): the Gaussian head that consumes this net's states (GaussianLayer,
+     simple_fhvae.py:193-216; f32 master weights head_w_mu / head_w_lv [head_D, head_K]).  The forward's operand-cast launch then
+     also writes the head's stacked bf16 operands -- head_wl [2 head_D, head_K] = [W_mu; W_lv] and head_wt [head_K, head_ldt] =
+     [W_mu^T | W_lv^T | 0] (head_ldt >= 2 head_D), exactly what fhvae_head_pair_weights produces -- instead of one more launch per
+     head and step. */
+  const float* head_w_mu;
+  const float* head_w_lv;
+  void* head_wl;
+  void* head_wt;
+  int64_t head_D, head_K, head_ldt;
   int32_t* sticky_status; /* BF16 mode, optional (may be NULL): int32 device word that the library never clears.  A persistent
                     launch that gives up ORs its status code into it as well as into the workspace's status word (which
                     the next forward on that workspace re-arms): the failure stays visible however late the host looks. */
@@ -316,7 +330,8 @@ int64_t fhvae_elbo_colsum_rows(int64_t B);
  * fwd writes per-query partials so that a row-sharded table can be combined across GPUs:
  *   row_max[b], row_sumexp[b] over THIS table's rows, tgt_logit[b] = logit at row idx[b]-row0
  *   (0 if that row is not in [row0, row0+S)), and, if ce_mean != NULL, the single-shard scalar
- *   ce_mean = mean_b( (row_max - tgt_logit) + log(row_sumexp) )  (= the reference's log_qy).
+ *   ce_mean = ce_scale * mean_b( (row_max - tgt_logit) + log(row_sumexp) )  (ce_scale = 1: the reference's log_qy,
+ *   simple_fhvae.py:122; -1: the intended objective's -CE without a negation launch each way).
  * ws: workspace of fhvae_disc_lse_ws_bytes(B,S) bytes.
  * dtype (fwd and bwd; q, table and every output stay f32): FHVAE_F32 = the logits in exact f32 (direct form on the VALU, or
  * the expanded form on exact-f32 MFMA for D = 32 and B*S >= 65536) -- the parity mode; FHVAE_BF16 (D = 32 large problems
@@ -326,7 +341,7 @@ int64_t fhvae_elbo_colsum_rows(int64_t B);
 int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S);
 int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
                        float inv_two_var, float* row_max, float* row_sumexp, float* tgt_logit,
-                       float* ce_mean, void* ws, int64_t B, int64_t S, int64_t D, int dtype, void* stream);
+                       float* ce_mean, float ce_scale, void* ws, int64_t B, int64_t S, int64_t D, int dtype, void* stream);
 /* Helpers of the row-sharded table's exchange (the reference has no distributed code): one launch each.
  * pack / unpack: [q[b, 0..D) | int32 bits of idx[b]] rows of D+1 floats -- queries and row indices travel in one all-gather.
  * merge_partials: the W ranks' K5 partials, parts[w] = [row_max | row_sumexp | tgt_logit] of N queries each, merged into the
@@ -342,7 +357,7 @@ int fhvae_shard_bwd_pack(const float* dq_all, float dq_scale, const float* dmu2_
 int fhvae_shard_bwd_unpack(const float* buf, int64_t own0, int64_t n_own, float* dq_local, float* dmu2_all, int64_t N, int64_t D,
                            void* stream);
 int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp, const float* tgt_logit,
-                       float* ce_mean, int64_t B, void* stream);
+                       float* ce_mean, float ce_scale, int64_t B, void* stream);
 
 /* bwd: given the GLOBAL (all shards combined) row_max[b] and row_sumexp[b] and the scalar scale
  * g = (*g_scale) * g_mul  (= dL/d(ce_mean) / B_total), computes  p[b,s] = exp(logit - row_max[b]) / row_sumexp[b]
@@ -351,12 +366,16 @@ int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp, const floa
  *   dq[b,:]     = sum_s w * (-2 c)(q[b]-t[s])      OVERWRITTEN  (partial over this shard's rows)
  *   dtable[s,:] += sum_b w * (+2 c)(q[b]-t[s])     ACCUMULATED
  * g is read from device memory (g_scale, one f32) so the call stays graph-capturable.
- * ws: fhvae_disc_lse_bwd_ws_bytes(B,S,D) bytes of workspace (16-byte aligned), or NULL.  With it (and dq and dtable both wanted) the kernels that
- * have a one-pass form take both gradients from ONE recomputation of the logits; without it, one pass per gradient. */
+ * ws / ws_bytes: workspace (16-byte aligned) or NULL / 0.  With it (and dq and dtable both wanted) the kernels that have a one-pass
+ * form take both gradients from ONE recomputation of the logits; without it, one pass per gradient.  The one-pass form keeps
+ * (B/256) x S x (D+1) floats of partial sums: fhvae_disc_lse_bwd_ws_bytes(B,S,D) is the RECOMMENDED size, capped at 1.5 GiB (the
+ * partials of B = 16384 queries against 10^6 rows would be 8.4 GB); with fewer bytes than the whole problem needs the queries
+ * are processed in groups of as many 256-query tiles as fit (any size from one tile's partials up works; below that the
+ * call takes the two-pass form).  0 from the size function = no one-pass form for this shape. */
 int64_t fhvae_disc_lse_bwd_ws_bytes(int64_t B, int64_t S, int64_t D);
 int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0,
                        float inv_two_var, const float* row_max, const float* row_sumexp,
-                       const float* g_scale, float g_mul, float* dq, float* dtable, void* ws,
+                       const float* g_scale, float g_mul, float* dq, float* dtable, void* ws, int64_t ws_bytes,
                        int64_t B, int64_t S, int64_t D, int dtype, void* stream);
 
 /* The discriminative segment variational lower bound, train_model.py:243-251:

@@ -34,12 +34,15 @@ int64_t disc_mfma_ws_bytes(int64_t B, int64_t S);
 // lp != 0: the bf16 split-operand kernels (D == 32 only; otherwise the f32 ones run)
 int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
                   int64_t B, int64_t S, int64_t D, int lp, hipStream_t st);
-// ws: disc_onepass_ws_bytes(B, S, D) of workspace (or NULL): with it, dq AND dtable wanted and a kernel that has the one-pass
-// form, both gradients come from one recomputation of the logits; otherwise one pass per gradient
+// ws / ws_bytes: workspace (or NULL / 0): with it, dq AND dtable wanted and a kernel that has the one-pass form, both gradients
+// come from one recomputation of the logits, the queries in groups of as many 256-query tiles as the workspace holds the
+// partial sums of; otherwise (or with less than one tile's worth) one pass per gradient.  disc_onepass_ws_bytes = the
+// recommended size: the whole problem in one group up to kOnePassWsCap.
+constexpr int64_t kOnePassWsCap = 3LL << 29;  // 1.5 GiB
 int64_t disc_onepass_ws_bytes(int64_t B, int64_t S, int64_t D);
 int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
-                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, float* ws, int64_t B, int64_t S,
-                  int64_t D, int lp, hipStream_t st);
+                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, float* ws, int64_t ws_bytes,
+                  int64_t B, int64_t S, int64_t D, int lp, hipStream_t st);
 // disc_lp.hip
 void disc_lp_launch(const DiscMfmaArgs& a, int mode, dim3 grid, hipStream_t st);
 

@@ -15,6 +15,8 @@
 // with w = g (softmax - onehot) recomputed from the per-query (max, sumexp) of the forward.  The logit tile comes out
 // of the MFMA with the stationary index on the lanes (col = lane&15) and the streamed index in the 4 accumulator
 // registers (row = 4*(lane>>4)+r): exactly the B-operand layout of the second product, so w never leaves registers.
+#include <algorithm>
+
 #include "disc_mfma.h"
 
 #include <cstdlib>
@@ -437,9 +439,27 @@ int64_t disc_mfma_ws_bytes(int64_t B, int64_t S) {
   return fh_cdiv(S, chunk) * B * (int64_t)sizeof(float2);
 }
 
+// one-pass backward: the queries go in groups of `tiles` 256-query tiles; a group needs its chunks' partials of dq
+// (nchunks x rows x D floats) and tiles x S x (D + 1) floats of the streamed side's partial sums
+static int64_t onepass_group_bytes(int64_t tiles, int64_t B, int64_t S, int64_t D) {
+  const int64_t rows = std::min<int64_t>(B, tiles * 256);
+  const int64_t nchunks = fh_cdiv(S, mfma_chunk(rows, S, 512));
+  return (nchunks * rows * D + tiles * S * (D + 1)) * (int64_t)sizeof(float);
+}
+// the most tiles per group (<= all of them) whose partials fit `bytes`; 0: not even one
+static int64_t onepass_group_tiles(int64_t bytes, int64_t B, int64_t S, int64_t D) {
+  const int64_t nxt = fh_cdiv(B, 256);
+  int64_t lo = 0, hi = nxt;  // (the size grows with the tile count)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) / 2;
+    if (onepass_group_bytes(mid, B, S, D) <= bytes) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
 int64_t disc_onepass_ws_bytes(int64_t B, int64_t S, int64_t D) {
-  const int64_t nchunks = fh_cdiv(S, mfma_chunk(B, S, 512)), nxt = fh_cdiv(B, 256);
-  return (nchunks * B * D + nxt * S * (D + 1)) * (int64_t)sizeof(float);
+  const int64_t t = onepass_group_tiles(kOnePassWsCap, B, S, D);
+  return t > 0 ? onepass_group_bytes(t, B, S, D) : 0;
 }
 
 int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, float2* part, int* nchunks,
@@ -467,8 +487,8 @@ int disc_mfma_fwd(const float* q, const float* table, const int64_t* idx, int64_
 }
 
 int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float c, const float* rmax,
-                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, float* ws, int64_t B, int64_t S,
-                  int64_t D, int lp, hipStream_t st) {
+                  const float* rsum, const float* gsc, float gmul, float* dq, float* dtable, float* ws, int64_t ws_bytes, int64_t B,
+                  int64_t S, int64_t D, int lp, hipStream_t st) {
   DiscMfmaArgs a = {};
   a.c = c;
   a.idx = idx;
@@ -477,31 +497,41 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
   a.rsum = rsum;
   a.gsc = gsc;
   a.gmul = gmul;
-  if (dq && dtable && ws && !getenv("FHVAE_DISC_TWO_PASS")) {
-    // one pass: stationary = queries, streamed = table rows; dq as in the two-pass form, dtable from the same weights
-    a.X = q;
-    a.Y = table;
-    a.NX = (int)B;
-    a.NY = (int)S;
-    a.x_is_query = 1;
-    a.chunk = mfma_chunk(B, S, 512);
-    const int64_t nchunks = fh_cdiv(S, a.chunk), nxt = fh_cdiv(B, 256);
-    a.G = ws;                      // [nchunks][B, D]
-    a.G2 = a.G + nchunks * B * D;  // [nxt][S, D]
-    a.WY = a.G2 + nxt * S * D;     // [nxt][S]
-    dim3 grid((unsigned)nchunks, (unsigned)nxt);
-    if (lp && D == 32)
-      disc_lp_launch(a, 2, grid, st);
-    else if (D == 32)
-      hipLaunchKernelGGL((disc_mfma_kernel<32, 2>), grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((disc_mfma_kernel<16, 2>), grid, dim3(256), 0, st, a);
-    int e = fh_launch_status();
-    if (e) return e;
-    hipLaunchKernelGGL(disc_dq_reduce_kernel, dim3((unsigned)fh_cdiv(B * D, 256)), dim3(256), 0, st, dq, a.G, (int)nchunks, B * D);
-    hipLaunchKernelGGL(disc_dt_finish_kernel, dim3((unsigned)fh_cdiv(S * D, 256)), dim3(256), 0, st, dtable, table, a.G2, a.WY, (int)nxt,
-                       2.f * c, S, (int)D);
-    return fh_launch_status();
+  const int64_t gtiles = (dq && dtable && ws && !getenv("FHVAE_DISC_TWO_PASS")) ? onepass_group_tiles(ws_bytes, B, S, D) : 0;
+  if (gtiles > 0) {
+    // one pass: stationary = queries, streamed = table rows; dq as in the two-pass form, dtable from the same weights.  Query
+    // groups of gtiles tiles, one after the other on the same workspace (dtable accumulates over the groups)
+    for (int64_t x0 = 0; x0 < B; x0 += gtiles * 256) {
+      const int64_t nb = std::min<int64_t>(B - x0, gtiles * 256), nxt = fh_cdiv(nb, 256);
+      a.X = q + x0 * D;
+      a.Y = table;
+      a.NX = (int)nb;
+      a.NY = (int)S;
+      a.x_is_query = 1;
+      a.idx = idx + x0;
+      a.rmax = rmax + x0;
+      a.rsum = rsum + x0;
+      a.chunk = mfma_chunk(nb, S, 512);
+      const int64_t nchunks = fh_cdiv(S, a.chunk);
+      a.G = ws;                       // [nchunks][nb, D]
+      a.G2 = a.G + nchunks * nb * D;  // [nxt][S, D]
+      a.WY = a.G2 + nxt * S * D;      // [nxt][S]
+      dim3 grid((unsigned)nchunks, (unsigned)nxt);
+      if (lp && D == 32)
+        disc_lp_launch(a, 2, grid, st);
+      else if (D == 32)
+        hipLaunchKernelGGL((disc_mfma_kernel<32, 2>), grid, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((disc_mfma_kernel<16, 2>), grid, dim3(256), 0, st, a);
+      int e = fh_launch_status();
+      if (e) return e;
+      hipLaunchKernelGGL(disc_dq_reduce_kernel, dim3((unsigned)fh_cdiv(nb * D, 256)), dim3(256), 0, st, dq + x0 * D, a.G, (int)nchunks, nb * D);
+      hipLaunchKernelGGL(disc_dt_finish_kernel, dim3((unsigned)fh_cdiv(S * D, 256)), dim3(256), 0, st, dtable, table, a.G2, a.WY, (int)nxt,
+                         2.f * c, S, (int)D);
+      e = fh_launch_status();
+      if (e) return e;
+    }
+    return FHVAE_OK;
   }
   if (dq) {  // stationary = queries, streamed = table rows; the workgroups ADD their partial gradients: zero first
     hipError_t he = hipMemsetAsync(dq, 0, (size_t)(B * D) * sizeof(float), st);

@@ -557,13 +557,20 @@ __global__ void reparam_pair_fwd_kernel(const float* __restrict__ out, int64_t l
   if (lv_c) lv_c[i] = lv;
 }
 
-// thread = 8 consecutive columns of a row of g (one 16-byte store); columns [2D, ldg) are zero
-__global__ void reparam_bwd_pair_kernel(const float* __restrict__ d_mu, const float* __restrict__ d_lv, const float* __restrict__ d_s,
-                                        const float* __restrict__ eps, const float* __restrict__ lv, int64_t ld_lv,
-                                        u16* __restrict__ g, int64_t ldg, int64_t M, int D) {
+// thread = 8 consecutive columns of a row of g (one 16-byte store); columns [2D, ldg) are zero.  DB: the workgroup's rows
+// (256 / (ldg / 8) whole rows) are also summed per column through LDS and added to the two bias gradients, one atomic per column
+// and workgroup -- the column-sum launch that used to follow (colsum_kernel over g) is gone
+template <bool DB>
+__global__ __launch_bounds__(256) void reparam_bwd_pair_kernel(const float* __restrict__ d_mu, const float* __restrict__ d_lv,
+                                                               const float* __restrict__ d_s, const float* __restrict__ eps,
+                                                               const float* __restrict__ lv, int64_t ld_lv, u16* __restrict__ g,
+                                                               int64_t ldg, int64_t M, int D, float* __restrict__ db_mu,
+                                                               float* __restrict__ db_lv) {
+  __shared__ float tile[DB ? 2048 : 1];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int per = (int)(ldg / 8);
-  if (i >= M * per) return;
+  const bool live = i < M * per;
+  if (!DB && !live) return;
   const int64_t m = i / per;
   const int c0 = (int)(i - m * per) * 8;
   union {
@@ -574,15 +581,26 @@ __global__ void reparam_bwd_pair_kernel(const float* __restrict__ d_mu, const fl
   for (int k = 0; k < 8; ++k) {
     const int c = c0 + k;
     float v = 0.f;
-    if (c < D) {
+    if (live && c < D) {
       v = (d_mu ? d_mu[m * D + c] : 0.f) + (d_s ? d_s[m * D + c] : 0.f);
-    } else if (c < 2 * D) {
+    } else if (live && c < 2 * D) {
       const int64_t j = m * D + (c - D);
       v = (d_lv ? d_lv[j] : 0.f) + ((d_s && eps) ? d_s[j] * eps[j] * 0.5f * expf(0.5f * lv[m * ld_lv + (c - D)]) : 0.f);
     }
     o.h[k] = f2bf(v);
+    if (DB) tile[threadIdx.x * 8 + k] = bf2f(o.h[k]);  // (the rounded value: what the weight-gradient contraction multiplies too)
   }
-  *(uint4*)(g + m * ldg + c0) = o.v;
+  if (live) *(uint4*)(g + m * ldg + c0) = o.v;
+  if (DB) {
+    __syncthreads();
+    const int rows = 256 / per;  // whole rows of this workgroup: flat index row * ldg + column
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+      float sum = 0.f;
+      for (int r = 0; r < rows; ++r) sum += tile[r * (int)ldg + c];
+      float* dst = c < D ? (db_mu ? db_mu + c : nullptr) : (db_lv ? db_lv + (c - D) : nullptr);
+      if (dst) atomicAdd(dst, sum);
+    }
+  }
 }
 
 // a[0..D) += column sums of src[rows][2D] (columns [0, D)), b likewise (columns [D, 2D)).  grid = (64-column groups, row
@@ -796,17 +814,26 @@ extern "C" int fhvae_gauss_reparam_pair_fwd(const float* out, int64_t ldo, const
 }
 
 extern "C" int fhvae_gauss_reparam_bwd_pair(const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
-                                            const float* logvar, int64_t ld_lv, void* g_lp, int64_t ldg, int64_t M, int64_t D,
-                                            void* stream) {
+                                            const float* logvar, int64_t ld_lv, void* g_lp, int64_t ldg, float* db_mu, float* db_lv,
+                                            int64_t M, int64_t D, void* stream) {
   FH_CHECK_PTR(g_lp);
   FH_CHECK_POS(M);
   FH_CHECK_POS(D);
   if (d_sample && (!eps || !logvar)) return FHVAE_ERR_NULL;
   if (ldg < 2 * D || ldg % 8) return FHVAE_ERR_SHAPE;
   if (((uintptr_t)g_lp) & 15) return FHVAE_ERR_ALIGN;
-  hipLaunchKernelGGL(reparam_bwd_pair_kernel, dim3((unsigned)fh_cdiv(M * (ldg / 8), 256)), dim3(256), 0, (hipStream_t)stream, d_mu,
-                     d_logvar, d_sample, eps, logvar, ld_lv, (u16*)g_lp, ldg, M, (int)D);
-  return fh_launch_status();
+  const dim3 grid((unsigned)fh_cdiv(M * (ldg / 8), 256));
+  hipStream_t st = (hipStream_t)stream;
+  if ((db_mu || db_lv) && 256 % (ldg / 8) == 0) {  // whole rows per workgroup: the bias gradients' column sums ride along
+    hipLaunchKernelGGL(reparam_bwd_pair_kernel<true>, grid, dim3(256), 0, st, d_mu, d_logvar, d_sample, eps, logvar, ld_lv, (u16*)g_lp,
+                       ldg, M, (int)D, db_mu, db_lv);
+    return fh_launch_status();
+  }
+  hipLaunchKernelGGL(reparam_bwd_pair_kernel<false>, grid, dim3(256), 0, st, d_mu, d_logvar, d_sample, eps, logvar, ld_lv, (u16*)g_lp, ldg,
+                     M, (int)D, nullptr, nullptr);
+  int e = fh_launch_status();
+  if (e || !(db_mu || db_lv)) return e;
+  return launch_colsum(g_lp, FHVAE_BF16, ldg, db_mu, db_lv, M, 2 * D, st, D);
 }
 
 extern "C" int fhvae_gauss_head_bwd_pair(const void* h_lp, int64_t ldh, const void* wt_pair, int64_t ldt, const void* g_lp, int64_t ldg,

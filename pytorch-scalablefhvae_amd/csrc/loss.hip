@@ -437,14 +437,14 @@ __global__ __launch_bounds__(256) void disc_own_bwd_kernel(const float* __restri
 
 // single-workgroup deterministic mean of (max + log(sumexp) - target)
 __global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ row_max, const float* __restrict__ row_sum,
-                                                      const float* __restrict__ tgt, float* __restrict__ out, int B) {
+                                                      const float* __restrict__ tgt, float* __restrict__ out, int B, float scale) {
   __shared__ float red[4];
   float s = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) s += (row_max[b] - tgt[b]) + logf(row_sum[b]);  // exact 0 + log s when the target row is the max
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+  if (threadIdx.x == 0) *out = scale * ((red[0] + red[1] + red[2] + red[3]) / (float)B);
 }
 
 // loss = -(mean(lower_bound) + alpha * log_qy)  (train_model.py:243-251) in one launch, and its backward in one
@@ -843,8 +843,8 @@ extern "C" int64_t fhvae_disc_lse_ws_bytes(int64_t B, int64_t S) {
   }
 
 extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float inv_two_var,
-                                  float* row_max, float* row_sumexp, float* tgt_logit, float* ce_mean, void* ws, int64_t B,
-                                  int64_t S, int64_t D, int dtype, void* stream) {
+                                  float* row_max, float* row_sumexp, float* tgt_logit, float* ce_mean, float ce_scale, void* ws,
+                                  int64_t B, int64_t S, int64_t D, int dtype, void* stream) {
   if (dtype != FHVAE_F32 && dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
   FH_CHECK_PTR(q);
   FH_CHECK_PTR(table);
@@ -877,7 +877,7 @@ extern "C" int fhvae_disc_lse_fwd(const float* q, const float* table, const int6
   e = fh_launch_status();
   if (e) return e;
   if (ce_mean) {
-    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, row_max, row_sumexp, tgt_logit, ce_mean, (int)B);
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, row_max, row_sumexp, tgt_logit, ce_mean, (int)B, ce_scale);
     e = fh_launch_status();
   }
   return e;
@@ -934,7 +934,7 @@ extern "C" int fhvae_shard_bwd_unpack(const float* buf, int64_t own0, int64_t n_
 }
 
 extern "C" int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp, const float* tgt_logit, float* ce_mean,
-                                  int64_t B, void* stream) {
+                                  float ce_scale, int64_t B, void* stream) {
   FH_CHECK_PTR(row_max);
   FH_CHECK_PTR(row_sumexp);
   FH_CHECK_PTR(tgt_logit);
@@ -942,13 +942,14 @@ extern "C" int fhvae_disc_ce_mean(const float* row_max, const float* row_sumexp,
   FH_CHECK_POS(B);
   FH_CHECK_I32(B);
   hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_max, row_sumexp, tgt_logit, ce_mean,
-                     (int)B);
+                     (int)B, ce_scale);
   return fh_launch_status();
 }
 
 extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int64_t* idx, int64_t row0, float inv_two_var,
                                   const float* row_max, const float* row_sumexp, const float* g_scale, float g_mul,
-                                  float* dq, float* dtable, void* ws, int64_t B, int64_t S, int64_t D, int dtype, void* stream) {
+                                  float* dq, float* dtable, void* ws, int64_t ws_bytes, int64_t B, int64_t S, int64_t D, int dtype,
+                                  void* stream) {
   if (dtype != FHVAE_F32 && dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
   FH_CHECK_PTR(q);
   FH_CHECK_PTR(table);
@@ -962,8 +963,9 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
   FH_CHECK_I32(S);
   hipStream_t st = (hipStream_t)stream;
   if (disc_mfma_supported(B, S, D) && !getenv("FHVAE_DISC_VALU")) {
-    int e = disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, (float*)ws, B, S, D,
-                          dtype == FHVAE_BF16, st);
+    if (ws && (((uintptr_t)ws) & 15)) return FHVAE_ERR_ALIGN;
+    int e = disc_mfma_bwd(q, table, idx, row0, inv_two_var, row_max, row_sumexp, g_scale, g_mul, dq, dtable, (float*)ws,
+                          ws ? ws_bytes : 0, B, S, D, dtype == FHVAE_BF16, st);
     if (e) return e;
     if (dq || dtable) {
       DISC_DISPATCH(D, hipLaunchKernelGGL((disc_own_bwd_kernel<DD>), dim3((unsigned)fh_cdiv(B * (DD / 4), 256)), dim3(256), 0, st, q,

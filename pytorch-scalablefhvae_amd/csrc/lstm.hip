@@ -220,14 +220,16 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_step_kernel(BwdJobs<T> jobs
 struct CastItem {
   const float* src;
   u16* dst;    // [R,C] or NULL
-  u16* dst_t;  // [C,R] or NULL
+  u16* dst_t;  // [C,R] (row stride ld_t) or NULL
   int64_t R, C;
+  int64_t ld_t;  // row stride of dst_t (0: R)
+  int64_t pad_t; // columns [R, R + pad_t) of every dst_t row are zeroed (the head's [W_mu^T | W_lv^T | 0])
 };
 struct CastBatch {
   unsigned* sync;  // the workspace's sync block (lstm_cluster.h): cleared here, once per forward
   int* sticky;     // fhvae_lstm_desc.sticky_status: its address is left in the block for cluster_give_up
   int n;
-  CastItem it[4 * FHVAE_MAX_LAYERS + 2];
+  CastItem it[4 * FHVAE_MAX_LAYERS + 4];
 };
 // 32x32 tiles: coalesced f32 reads, coalesced bf16 writes of the straight copy, and the transposed copy through an LDS tile
 // (the element-wise version wrote the transpose as 2-byte scatters: 13-15 us per net, now ~4)
@@ -259,7 +261,9 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(CastBatch cb) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int64_t cc = c0 + ty + 8 * k, r = r0 + tx;
-        if (cc < c.C && r < c.R) c.dst_t[cc * c.R + r] = tile[tx][ty + 8 * k];
+        if (cc < c.C && r < c.R) c.dst_t[cc * (c.ld_t ? c.ld_t : c.R) + r] = tile[tx][ty + 8 * k];
+        if (c.pad_t > 0 && r0 == 0 && cc < c.C)
+          for (int64_t j = tx; j < c.pad_t; j += 32) c.dst_t[cc * c.ld_t + c.R + j] = 0;
       }
       __syncthreads();
     }
@@ -341,6 +345,14 @@ static int check_desc(const fhvae_lstm_desc* d) {
   if ((((uintptr_t)d->hs) | ((uintptr_t)d->cs) | ((uintptr_t)d->gates)) & 15) return FHVAE_ERR_ALIGN;
   for (int l = 0; l < d->L; ++l)
     if ((((uintptr_t)d->w_ih[l]) | ((uintptr_t)d->w_hh[l])) & 15) return FHVAE_ERR_ALIGN;
+  if (d->head_w_mu) {  // the head's stacked operands ride in the operand-cast launch: bf16 mode only
+    if (d->dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
+    FH_CHECK_PTR(d->head_w_lv);
+    if (!d->head_wl && !d->head_wt) return FHVAE_ERR_NULL;
+    FH_CHECK_POS(d->head_D);
+    FH_CHECK_POS(d->head_K);
+    if (d->head_wt && d->head_ldt < 2 * d->head_D) return FHVAE_ERR_SHAPE;
+  }
   return FHVAE_OK;
 }
 
@@ -453,7 +465,7 @@ static int cast_operands(const fhvae_lstm_desc* d, hipStream_t st) {
   cb.sync = (unsigned*)d->lp;
   cb.sticky = d->sticky_status;
   auto add = [&](const float* s, u16* dst, u16* dst_t, int64_t R, int64_t C) {
-    if (R * C > 0) cb.it[cb.n++] = CastItem{s, dst, dst_t, R, C};
+    if (R * C > 0) cb.it[cb.n++] = CastItem{s, dst, dst_t, R, C, 0, 0};
   };
   if (!d->x_lp) add(d->x, base + L.x, nullptr, d->T * d->B, d->I);
   add(d->xc, base + L.xc, nullptr, d->B, d->Ic);
@@ -461,6 +473,13 @@ static int cast_operands(const fhvae_lstm_desc* d, hipStream_t st) {
     const int64_t kin = l == 0 ? d->I + d->Ic : d->H;
     add(d->w_ih[l], base + L.w_ih[l], l == 0 ? nullptr : base + L.w_ih_t[l], 4 * d->H, kin);
     add(d->w_hh[l], base + L.w_hh[l], base + L.w_hh_t[l], 4 * d->H, d->H);
+  }
+  if (d->head_w_mu) {  // the stacked operands of the Gaussian head behind this net (fhvae_lstm_desc.head_*)
+    const int64_t D = d->head_D, K = d->head_K, ldt = d->head_ldt;
+    u16* wl = (u16*)d->head_wl;
+    u16* wt = (u16*)d->head_wt;
+    cb.it[cb.n++] = CastItem{d->head_w_mu, wl, wt, D, K, ldt, 0};
+    cb.it[cb.n++] = CastItem{d->head_w_lv, wl ? wl + D * K : nullptr, wt ? wt + D : nullptr, D, K, ldt, wt ? ldt - 2 * D : 0};
   }
   hipLaunchKernelGGL(cast_batch_kernel, dim3(256, (unsigned)cb.n), dim3(256), 0, st, cb);
   return fh_launch_status();
@@ -657,6 +676,11 @@ extern "C" int64_t fhvae_lstm_ws_below_elems(const fhvae_lstm_desc* d) {
   return cluster_needs_ws_below(d) ? d->T * d->B * d->H : 0;
 }
 
+__global__ void cast_hn_kernel(const float* __restrict__ s, u16* __restrict__ d, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = f2bf(s[i]);
+}
+
 extern "C" int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream) {
   int e = check_desc(d);
   if (e) return e;
@@ -678,7 +702,13 @@ extern "C" int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream) {
   }
   e = cast_operands(d, st);
   if (e) return e;
-  return lstm_fwd_impl<u16>(d, ops_bf16(d), st);
+  e = lstm_fwd_impl<u16>(d, ops_bf16(d), st);
+  if (e || !d->hn_lp) return e;
+  if (!d->hn) return FHVAE_ERR_NULL;
+  if (cluster_eligible(d) && cluster_fwd_wr_ok(d)) return FHVAE_OK;  // lstm_fwd_wr.hip stored the bf16 copy beside hn
+  const int64_t n = d->B * d->L * d->H;
+  hipLaunchKernelGGL(cast_hn_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, d->hn, (u16*)d->hn_lp, n);
+  return fh_launch_status();
 }
 
 // the backward jobs of wavefront step w (layer l at time T-1-(w-(L-1-l)))
@@ -898,7 +928,7 @@ static int lstm_param_grads(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, hip
 }
 
 // d_xc[B,Ic] = dgsum[B,4H] . W_ih0[:, I:]   (f32 master weight as KM operand: B(n, k) = W[k*K0 + I + n])
-static int lstm_dxc(const fhvae_lstm_bwd_desc* bd, hipStream_t st) {
+static int lstm_dxc(const fhvae_lstm_bwd_desc* bd, hipStream_t st, bool zeroed = false) {
   const fhvae_lstm_desc* d = &bd->f;
   if (!bd->d_xc || d->Ic <= 0) return FHVAE_OK;
   const int64_t G = 4 * d->H, K0 = d->I + d->Ic;
@@ -913,7 +943,7 @@ static int lstm_dxc(const fhvae_lstm_bwd_desc* bd, hipStream_t st) {
   const int64_t tiles = fh_cdiv(d->B, 64) * fh_cdiv(d->Ic, 64);
   if (tiles <= 64 && G >= 512) {
     const int64_t n = d->B * d->Ic;
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)fh_cdiv(n, 1024)), dim3(256), 0, st, bd->d_xc, n);
+    if (!zeroed) hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)fh_cdiv(n, 1024)), dim3(256), 0, st, bd->d_xc, n);
     p.mode = 2;
     p.splitk = 4;
   } else {
@@ -952,7 +982,7 @@ extern "C" int fhvae_lstm_seq_bwd(const fhvae_lstm_bwd_desc* bd, void* stream) {
   if (rec) {
     e = lstm_bwd_impl<u16>(bd, op, st);
     if (e) return e;
-    e = lstm_dxc(bd, st);
+    e = lstm_dxc(bd, st, cluster_eligible(d) && cluster_bwd_zeroes_dxc(d));
     if (e) return e;
   }
   if (!par) return FHVAE_OK;

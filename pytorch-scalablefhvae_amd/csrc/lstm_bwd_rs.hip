@@ -293,6 +293,12 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_layer_rs_kernel(ClBwd p) {
       dg_store(3, v3);
     }
   }
+  if (p.d_xc_zero && me == 0 && wave == 0) {  // one wave per cluster clears its rows of d_xc for the contraction that follows
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      if (row[rt] < rend)
+        for (int c = q; c < p.Ic; c += 4) p.d_xc_zero[(int64_t)row[rt] * p.Ic + c] = 0.f;
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     f32x4 vs = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -45,6 +45,8 @@ bool cluster_fwd_wr_ok(const fhvae_lstm_desc* d);
 int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t st);
 // the backward needs fhvae_lstm_bwd_desc.ws_below
 bool cluster_needs_ws_below(const fhvae_lstm_desc* d);
+// the backward recurrence leaves bd->d_xc zeroed (lstm_bwd_rs.hip): lstm.hip's split-K contraction into it needs no zeroing launch
+bool cluster_bwd_zeroes_dxc(const fhvae_lstm_desc* d);
 // the recurrence of fhvae_lstm_seq_bwd: fills dgates (and dgsum when Ic > 0)
 int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStream_t st);
 

@@ -1339,6 +1339,7 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     p.gates = (u16*)d->gates;
     p.hs_top_f32 = d->hs_top_f32;
     p.hn = d->hn;
+    p.hn_lp = wr ? (u16*)d->hn_lp : nullptr;
     p.sync = (unsigned*)d->lp;
     p.xch = w.xch;
     p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;
@@ -1469,6 +1470,7 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
       p.tlog_slot = l == L - 1;
       p.nt = 1;  // streaming hints on its once-read operands: HBM reads 202 -> 175 MB per launch (1.04x algorithmic), 0.5 % of a step
       p.gates_um = cluster_fwd_wr_ok(d) ? 1 : 0;  // the forward on this workspace saved the gates unit-major (same predicate)
+      if (rs && l == 0 && bd->d_xc && d->Ic > 0) p.d_xc_zero = bd->d_xc, p.Ic = (int)d->Ic;  // (cluster_bwd_zeroes_dxc)
       const int ts = trace_begin(st, kTraceBwdCell, 2.0 * nrows * H * (T - 1) * 4.0 * H);
       const int e = rs ? cluster_bwd_layer_rs(p, st) : (H == 256 ? launch_bwd_layer_rb<256>(p, RB, st) : launch_bwd_layer_rb<128>(p, RB, st));
       trace_end(st, ts);
@@ -1477,6 +1479,9 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
   }
   return FHVAE_OK;
 }
+
+// the partial-dh backward clears d_xc itself (its layer-0 launch covers every row once)
+bool cluster_bwd_zeroes_dxc(const fhvae_lstm_desc* d) { return cluster_bwd_rs(d); }
 
 // the layer-by-layer backward (rows form, two layers or more) hands the from-above gradient to the lower layer through
 // bd->ws_below (T,B,H) f32

@@ -171,6 +171,8 @@ struct ClBwd {
   int gates_um;          // the forward saved the gates unit-major (lstm_fwd_wr.hip): [row][unit][i,f,g,o] bf16
   int tlog_slot;         // lstm_bwd_rs.hip: which half of the phase-clock log this launch writes (tools/prof_rs.py)
   int nt;                // lstm_bwd_rs.hip: streaming (non-temporal) hints on the once-read operands and the once-written dg
+  float* d_xc_zero;      // lstm_bwd_rs.hip, layer 0: (B,Ic) f32 to ZERO for the rows of this launch (the split-K contraction that
+  int Ic;                // follows adds into it: the zeroing launch in front of it is gone), or NULL
 };
 
 __device__ __forceinline__ f32x4 unpack4(uint2 v) {
@@ -199,6 +201,7 @@ struct ClFwd {
   u16* gates;  // (L,T,B,4H)
   float* hs_top_f32;  // optional (T,B,H)
   float* hn;          // optional (B, L*H)
+  u16* hn_lp;         // optional (B, L*H) bf16 copy of hn (lstm_fwd_wr.hip)
   u16* xch;  // exchange buffer (blocked copy of h; contraction-split form), see xch_off
   unsigned* sync;
   unsigned long long* tlog;  // optional phase clock log of cluster 0 / member 0 (tools/prof_cluster.py)

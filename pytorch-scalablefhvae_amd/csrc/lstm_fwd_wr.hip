@@ -206,7 +206,13 @@ __global__ __launch_bounds__(kFwThreads) void lstm_fwd_wr_kernel(ClFwd p) {
           const uint4 hv = *(const uint4*)(st + ROWS * (kGS + kCS) + rw * kCS + part * 16);
           if (r0 + rw < rend) {
             if (top) *(uint4*)(p.hs_top_f32 + ((int64_t)t * B + r0 + rw) * H + um + part * 4) = hv;
-            if (last) *(uint4*)(p.hn + (int64_t)(r0 + rw) * (2 * H) + l * H + um + part * 4) = hv;
+            if (last) {
+              *(uint4*)(p.hn + (int64_t)(r0 + rw) * (2 * H) + l * H + um + part * 4) = hv;
+              if (p.hn_lp) {  // the latent head's bf16 operand (fhvae_lstm_desc.hn_lp)
+                const float4 hf = __builtin_bit_cast(float4, hv);
+                *(uint2*)(p.hn_lp + (int64_t)(r0 + rw) * (2 * H) + l * H + um + part * 4) = pack4(f32x4{hf.x, hf.y, hf.z, hf.w});
+              }
+            }
           }
         }
       }

@@ -78,8 +78,8 @@ class HipBackend:
     def bwd_unpack(self, buf, own0, n_own, want_dq, want_dmu2):
         return self.hb.shard_bwd_unpack(buf, own0, n_own, want_dq, want_dmu2)
 
-    def ce_mean(self, m, s, tgt):
-        return self.hb.raw_disc_ce_mean(m, s, tgt)
+    def ce_mean(self, m, s, tgt, scale=1.0):
+        return self.hb.raw_disc_ce_mean(m, s, tgt, scale)
 
     def disc_bwd(self, q_all, shard, idx_all, row0, m, s, g, g_mul, need_dq, need_dt):
         if shard.shape[0] == 0:
@@ -158,8 +158,9 @@ class _ShardTable(torch.autograd.Function):
     GLOBAL batch, identical on every rank).  Three collectives forward, one backward (module docstring)."""
 
     @staticmethod
-    def forward(ctx, q_local, shard, idx_local, sh: ShardCtx):
+    def forward(ctx, q_local, shard, idx_local, sh: ShardCtx, sign=1.0):
         be = sh.backend
+        ctx.sign = float(sign)
         # (1) one buffer: the queries and, in the last column, the row indices as int32 bit patterns
         q_all, idx_all = be.unpack(sh.all_gather(be.pack(q_local, idx_local)))
         # (2) rows: zeros for rows owned elsewhere, so the sum over ranks is the row
@@ -167,7 +168,7 @@ class _ShardTable(torch.autograd.Function):
         # (3) K5 partials of this shard for ALL queries, merged locally (an empty shard's (-inf, 0) contributes nothing)
         parts = sh.all_gather(be.disc_partials(q_all, shard, idx_all, sh.row0)).view(sh.world, 3, -1)
         m, s, t = be.merge_partials(parts)
-        ce = be.ce_mean(m, s, t)
+        ce = be.ce_mean(m, s, t, ctx.sign)  # sign * CE (fhvae_core.FHVAEBase._tail)
         ctx.sh, ctx.shape = sh, tuple(shard.shape)
         ctx.sink = getattr(shard, "_fh_grad", None)
         ctx.save_for_backward(q_all, shard, idx_all, m, s)
@@ -185,7 +186,7 @@ class _ShardTable(torch.autograd.Function):
         if g is not None and (need_dq or need_dt):
             # one call for both sides (true scale 1/B_global: the shard's gradient is complete locally, all global queries were
             # scanned); the query side is averaged over ranks with the net gradients afterwards, so it carries W/B_global
-            dq_all, dshard = be.disc_bwd(q_all, shard, idx_all, sh.row0, m, s, g.reshape(1).contiguous(), 1.0 / n_all, need_dq, need_dt)
+            dq_all, dshard = be.disc_bwd(q_all, shard, idx_all, sh.row0, m, s, g.reshape(1).contiguous(), ctx.sign / n_all, need_dq, need_dt)
         # (4) [dq for all queries | dmu2 of the local queries in their rows], summed over the ranks
         buf = be.bwd_pack(dq_all, float(sh.world), dmu2, sh.rank * n_loc, n_all, D)
         sh.all_reduce_(buf)
@@ -197,7 +198,7 @@ class _ShardTable(torch.autograd.Function):
                 dshard = sink
             # the objective is the mean over ranks of the local losses: 1/W on every rank's mu2 contribution
             be.scatter_rows_(sink, dmu2_all, idx_all, sh.row0, 1.0 / sh.world)
-        return dq_local, dshard, None, None
+        return dq_local, dshard, None, None, None
 
 
 class ShardedTableOps:
@@ -215,8 +216,8 @@ class ShardedTableOps:
         self._idx = mu_idx
         return self.shard, None  # the rows arrive with the CE in resolve(): one exchange for both
 
-    def resolve(self, z2_mu, table, mu_idx, mu2):
-        mu2, ce, _ = _ShardTable.apply(z2_mu, self.shard, self._idx if mu_idx is None else mu_idx, self.sh)
+    def resolve(self, z2_mu, table, mu_idx, mu2, sign=1.0):
+        mu2, ce, _ = _ShardTable.apply(z2_mu, self.shard, self._idx if mu_idx is None else mu_idx, self.sh, float(sign))
         return mu2, ce
 
 
@@ -383,6 +384,11 @@ class DistributedFHVAE:
 
         import hip_binding as hb
 
+        # an early all-reduce left over from a step whose backward raised after it was issued: wait it out and forget it, or this
+        # step would skip its own early all-reduce and reduce only the last bucket
+        if self._pending not in (None, False):
+            self._pending.wait()
+        self._pending = None
         self.opt_nets.zero_grad()
         self.opt_table.zero_grad()
         out = self.model(x, idx, self.sh.S, nsegs)

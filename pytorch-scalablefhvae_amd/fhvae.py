@@ -52,10 +52,10 @@ class LSTMNet(nn.Module):
             raise ValueError("all layers of one LSTM net must share the hidden size (got %s)" % (hus,))
         self.lstm = LSTMParams(input_size, hus[0], len(hus))
 
-    def forward(self, x_tm, xc, T, dtype=hb.F32, top=2):
+    def forward(self, x_tm, xc, T, dtype=hb.F32, top=2, head=None):
         """x_tm (T,B,I) time-major or None; xc (B,Ic) constant-over-time extra input or None.
-        Returns (top-layer h_t (T,B,H), concat of final h of all layers (B, L*H)).  `top`: hip_binding.lstm_seq."""
-        return hb.lstm_seq(x_tm, xc, T, self.lstm.flat(), dtype, top)
+        Returns (top-layer h_t (T,B,H), concat of final h of all layers (B, L*H)).  `top`, `head`: hip_binding.lstm_seq."""
+        return hb.lstm_seq(x_tm, xc, T, self.lstm.flat(), dtype, top, head.head_weights() if (head is not None and dtype == hb.BF16) else None)
 
 
 class FHVAE(FHVAEBase):
@@ -115,17 +115,22 @@ class FHVAE(FHVAEBase):
         # f32 copy of the per-step states is not written at all (top=0 / top=1)
         # bf16 mode: the latent heads contract bf16 copies of the final states too (the nets that produced them ran on bf16
         # operands; hip_binding.gauss_head's condition on the sizes)
-        lp = (lambda h, dim: hb.cast_bf16(h) if (dt == hb.BF16 and h.shape[1] % 8 == 0 and dim % 8 == 0) else None)
-        _, hn2 = self.z2_pre_encoder(x_tm, None, T, dt, top=0)
-        z2_mu, z2_logvar, z2_sample = self.z2_gauss_layer(hn2, e2, input_lp=lp(hn2, self.z2_dim))
-        _, hn1 = self.z1_pre_encoder(x_tm, z2_sample, T, dt, top=0)
-        z1_mu, z1_logvar, z1_sample = self.z1_gauss_layer(hn1, e1, input_lp=lp(hn1, self.z1_dim))
+        # (the nets' forward leaves that copy beside hn: `_fh_lp`)
+        lp = (lambda h, dim: (getattr(h, "_fh_lp", None) if getattr(h, "_fh_lp", None) is not None else hb.cast_bf16(h))
+              if (dt == hb.BF16 and h.shape[1] % 8 == 0 and dim % 8 == 0) else None)
+        # (each net's operand-cast launch also makes the stacked bf16 weights of the head behind it: `_fh_head`)
+        _, hn2 = self.z2_pre_encoder(x_tm, None, T, dt, top=0, head=self.z2_gauss_layer)
+        z2_mu, z2_logvar, z2_sample = self.z2_gauss_layer(hn2, e2, input_lp=lp(hn2, self.z2_dim), shadows=getattr(hn2, "_fh_head", None))
+        _, hn1 = self.z1_pre_encoder(x_tm, z2_sample, T, dt, top=0, head=self.z1_gauss_layer)
+        z1_mu, z1_logvar, z1_sample = self.z1_gauss_layer(hn1, e1, input_lp=lp(hn1, self.z1_dim), shadows=getattr(hn1, "_fh_head", None))
         lp_head = dt == hb.BF16 and self.x_hus[-1] % 8 == 0 and F_ % 8 == 0  # (hip_binding.gauss_head's condition)
-        hs_top, _ = self.pre_decoder(None, torch.cat([z1_sample, z2_sample], dim=-1), T, dt, top=1 if lp_head else 2)
+        hs_top, _ = self.pre_decoder(None, torch.cat([z1_sample, z2_sample], dim=-1), T, dt, top=1 if lp_head else 2,
+                                     head=self.dec_gauss_layer)
         H = hs_top.shape[-1]
         hs_lp = getattr(hs_top, "_fh_lp", None)  # bf16 mode: the top layer's h in bf16 = the per-frame head's operand
         x_mu, x_logvar, _ = self.dec_gauss_layer(hs_top.reshape(T * B, H), sample=False,  # (T*B, F) time-major
-                                                 input_lp=hs_lp.reshape(T * B, H) if hs_lp is not None else None)
+                                                 input_lp=hs_lp.reshape(T * B, H) if hs_lp is not None else None,
+                                                 shadows=getattr(hs_top, "_fh_head", None))
 
         layout = (B, T, F_, (F_, B * F_), (F_, B * F_))  # x_tm and x_mu/x_logvar are all time-major
         return self._tail(x_tm, layout, x_mu, x_logvar, (z1_mu, z1_logvar), (z2_mu, z2_logvar), mu2, mu2_table, mu_idx,

@@ -27,13 +27,13 @@ class LocalTableOps:
         table = mu2_table if mu2_table is not None else self.model._table(num_seqs, mu_idx.device)
         return table, hb.mu2_gather(table, mu_idx)
 
-    def disc(self, z2_mu, table, mu_idx):
-        return hb.disc_lse(z2_mu, table, mu_idx, lp=getattr(self.model, "compute_dtype", "f32") == "bf16")
+    def disc(self, z2_mu, table, mu_idx, sign=1.0):
+        return hb.disc_lse(z2_mu, table, mu_idx, lp=getattr(self.model, "compute_dtype", "f32") == "bf16", sign=sign)
 
-    def resolve(self, z2_mu, table, mu_idx, mu2):
-        """(mu2 of the batch, CE against the whole table): the two things the loss tail needs from the table.  One call so that a
-        sharded table can serve both from ONE exchange (dist_shard.ShardedTableOps.resolve)."""
-        return mu2, self.disc(z2_mu, table, mu_idx)
+    def resolve(self, z2_mu, table, mu_idx, mu2, sign=1.0):
+        """(mu2 of the batch, sign * CE against the whole table): the two things the loss tail needs from the table.  One call so
+        that a sharded table can serve both from ONE exchange (dist_shard.ShardedTableOps.resolve)."""
+        return mu2, self.disc(z2_mu, table, mu_idx, sign)
 
 
 class FHVAEBase(nn.Module):
@@ -111,7 +111,10 @@ class FHVAEBase(nn.Module):
     def _draw(self, eps, B, device):
         if eps is not None:
             return eps[0].to(device), eps[1].to(device)
-        # reference draw order after the table: eps_z2 then eps_z1
+        # reference draw order after the table: eps_z2 then eps_z1; equal widths: one generator launch for both
+        if self.z1_dim == self.z2_dim:
+            e = torch.randn(2, B, self.z2_dim, device=device)
+            return e[0], e[1]
         e2 = torch.randn(B, self.z2_dim, device=device)
         e1 = torch.randn(B, self.z1_dim, device=device)
         return e2, e1
@@ -119,9 +122,9 @@ class FHVAEBase(nn.Module):
     def _tail(self, x_like, layout, x_mu, x_lv, z1, z2, mu2, table, mu_idx, num_segs):
         """simple_fhvae.py:105-124 on the HIP kernels."""
         rc = self.reference_compat
-        mu2, ce = self.table_ops.resolve(z2[0], table, mu_idx, mu2)
+        # log_qy = +CE literally (simple_fhvae.py:122) / -CE for the intended objective: the sign rides in the K5 kernels
+        mu2, log_qy = self.table_ops.resolve(z2[0], table, mu_idx, mu2, 1.0 if rc else -1.0)
         lb, lpx, nk1, nk2, lpm = hb.elbo(x_like, x_mu, x_lv, z1[0], z1[1], z2[0], z2[1], mu2, num_segs, layout, rc)
-        log_qy = ce if rc else -ce
         self.qz2_x = [z2[0], z2[1]]      # read by estimate_mu2_dict, utils.py:52
         self.pz2 = [mu2, PZ2_LOGVAR]     # utils.py:58
         return lb, log_qy, lpx, nk1, nk2, lpm

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
 
 F32, BF16 = 0, 1
 MAX_LAYERS = 4
-ABI_VERSION = 9  # FHVAE_ABI_VERSION of include/fhvae_hip.h
+ABI_VERSION = 10  # FHVAE_ABI_VERSION of include/fhvae_hip.h
 #: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
 INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
@@ -35,6 +35,8 @@ class LstmDesc(C.Structure):
         ("w_ih", _vp * MAX_LAYERS), ("w_hh", _vp * MAX_LAYERS),
         ("b_ih", _vp * MAX_LAYERS), ("b_hh", _vp * MAX_LAYERS),
         ("hs", _vp), ("cs", _vp), ("gates", _vp), ("hn", _vp), ("hs_top_f32", _vp), ("pre", _vp), ("lp", _vp),
+        ("hn_lp", _vp),
+        ("head_w_mu", _vp), ("head_w_lv", _vp), ("head_wl", _vp), ("head_wt", _vp), ("head_D", _i64), ("head_K", _i64), ("head_ldt", _i64),
         ("sticky_status", _vp),
     ]
 
@@ -91,7 +93,7 @@ SIGNATURES = {
     "fhvae_gauss_head_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_head_pair_weights": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_gauss_reparam_pair_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
-    "fhvae_gauss_reparam_bwd_pair": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
+    "fhvae_gauss_reparam_bwd_pair": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "fhvae_elbo_colsum_rows": (_i64, [_i64]),
     "fhvae_gauss_head_bwd_pair": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_loss_fwd": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _vp, _vp]),
@@ -115,13 +117,13 @@ SIGNATURES = {
     "fhvae_disc_merge_partials": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "fhvae_shard_bwd_pack": (C.c_int, [_vp, _f32, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
     "fhvae_shard_bwd_unpack": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
-    "fhvae_disc_ce_mean": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "fhvae_disc_ce_mean": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i64, _vp]),
     "fhvae_elbo_fwd": (C.c_int, [C.POINTER(ElboDesc), _vp]),
     "fhvae_elbo_bwd": (C.c_int, [C.POINTER(ElboBwdDesc), _vp]),
     "fhvae_disc_lse_ws_bytes": (_i64, [_i64, _i64]),
     "fhvae_disc_lse_bwd_ws_bytes": (_i64, [_i64, _i64, _i64]),
-    "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
-    "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp]),
+    "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _i64, C.c_int, _vp]),
+    "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, _vp]),
     "fhvae_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "fhvae_segment_gather": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "fhvae_mu2_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
@@ -461,9 +463,11 @@ class _GaussHead(torch.autograd.Function):
 
 # The upstream gradient of a head's (mu | logvar) pair buffer can arrive ready-made: fhvae_elbo_bwd writes the decoder-output
 # gradients a second time as the bf16 operand of the head's backward contractions, with their column sums (the bias
-# gradients).  _Elbo.backward leaves them here under the address of the f32 gradient buffer it returns to autograd; the head's
-# backward takes them only when the gradients autograd hands it ARE that buffer (same address and strides: nothing was
-# accumulated into or cast from it on the way).  One entry: the latest.
+# gradients).  _Elbo.backward leaves them here with the f32 gradient buffer it returns to autograd; the head's backward takes
+# them only when the gradients autograd hands it ARE views of that very tensor (identity of the base, same address and strides)
+# AND the buffer has not been written since the kernel filled it (version counter: an in-place hook such as g.mul_() keeps the
+# address but bumps the version).  One entry: the latest; every _Elbo.backward clears it first, so nothing stale survives a
+# backward that produced no side copy or a head that declined it.
 _PAIR_GRAD: dict = {}
 PAIR_SIDE = {"enabled": True, "used": 0}  # tests: switch the ready-made operand off / count how often a head took it
 
@@ -479,7 +483,9 @@ class _GaussHeadLp(torch.autograd.Function):
     g = [g_mu | g_lv].  Outputs, gradients and accumulation are f32."""
 
     @staticmethod
-    def forward(ctx, h, h_lp, w_mu, b_mu, w_lv, b_lv, eps):
+    def forward(ctx, h, h_lp, w_mu, b_mu, w_lv, b_lv, eps, shadows=None):
+        """shadows: (wl, wt) already produced for these weights in this step (the LSTM forward's operand-cast launch,
+        fhvae_lstm_desc.head_*), else one fhvae_head_pair_weights launch here."""
         _need_gpu(h, h_lp, w_mu, b_mu, w_lv, b_lv, eps)
         lib = load_library()
         ctx.set_materialize_grads(False)
@@ -490,9 +496,12 @@ class _GaussHeadLp(torch.autograd.Function):
         assert h_lp.dtype == torch.bfloat16 and h_lp.is_contiguous() and h.shape == h_lp.shape
         dev = h_lp.device
         ldg = _pair_ld(D)
-        wl = torch.empty(2 * D, K, device=dev, dtype=torch.bfloat16)   # [W_mu; W_lv]
-        wt = torch.empty(K, ldg, device=dev, dtype=torch.bfloat16)     # [W_mu^T | W_lv^T | 0]: the backward's operand
-        _check(lib.fhvae_head_pair_weights(_p(w_mu), _p(w_lv), _p(wl), _p(wt), ldg, D, K, _stream()), "fhvae_head_pair_weights")
+        if shadows is not None and tuple(shadows[0].shape) == (2 * D, K) and tuple(shadows[1].shape) == (K, ldg):
+            wl, wt = shadows
+        else:
+            wl = torch.empty(2 * D, K, device=dev, dtype=torch.bfloat16)   # [W_mu; W_lv]
+            wt = torch.empty(K, ldg, device=dev, dtype=torch.bfloat16)     # [W_mu^T | W_lv^T | 0]: the backward's operand
+            _check(lib.fhvae_head_pair_weights(_p(w_mu), _p(w_lv), _p(wl), _p(wt), ldg, D, K, _stream()), "fhvae_head_pair_weights")
         out = torch.empty(M, 2 * D, device=dev, dtype=torch.float32)
         with _Timed("fhvae_gauss_head_reparam_fwd"):
             _check(lib.fhvae_gauss_head_pair_fwd(_p(h_lp), K, _p(wl), _p(b_mu), _p(b_lv), _p(out), 2 * D, M, K, D, _stream()),
@@ -525,9 +534,11 @@ class _GaussHeadLp(torch.autograd.Function):
                 for k, shape in zip(sk, ((D, K), (D,), (D, K), (D,)))]
         dh = torch.empty(M, K, device=dev, dtype=torch.float32) if need_dh else None
         g_lp = colsum = None
+        db_done = False
         ready = _PAIR_GRAD.get("latest")
-        if (ready is not None and d_s is None and d_mu is not None and d_lv is not None and ready[0] == d_mu.data_ptr()
-                and d_lv.data_ptr() == ready[0] + 4 * D and d_mu.shape == (M, D) and d_lv.shape == (M, D)
+        if (ready is not None and d_s is None and d_mu is not None and d_lv is not None and ready[0].data_ptr() == d_mu.data_ptr()
+                and d_mu._base is ready[0] and d_lv._base is ready[0] and ready[0]._version == ready[3]
+                and d_lv.data_ptr() == d_mu.data_ptr() + 4 * D and d_mu.shape == (M, D) and d_lv.shape == (M, D)
                 and d_mu.stride() == (2 * D, 1) and d_lv.stride() == (2 * D, 1) and ready[1].shape == (M, ldg)):
             g_lp, colsum = ready[1], ready[2]
             _PAIR_GRAD.clear()
@@ -538,8 +549,10 @@ class _GaussHeadLp(torch.autograd.Function):
                 d_lv = _f32c(d_lv) if d_lv is not None else None
                 d_s = _f32c(d_s) if d_s is not None else None
                 g_lp = torch.empty(M, ldg, device=dev, dtype=torch.bfloat16)
-                _check(lib.fhvae_gauss_reparam_bwd_pair(_p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), lv.stride(0), _p(g_lp), ldg, M, D,
-                                                        _stream()), "fhvae_gauss_reparam_bwd_pair")
+                # (the two bias gradients = column sums of g_lp come out of the same launch)
+                _check(lib.fhvae_gauss_reparam_bwd_pair(_p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), lv.stride(0), _p(g_lp), ldg,
+                                                        _p(outs[1]), _p(outs[3]), M, D, _stream()), "fhvae_gauss_reparam_bwd_pair")
+                db_done = True
             # every parameter has a gradient sink: the two weight-gradient contractions join the nets' grouped launch
             xs = None
             if _DEFER["enabled"] and not _SIDE["enabled"] and all(k is not None for k in sk):
@@ -549,17 +562,27 @@ class _GaussHeadLp(torch.autograd.Function):
             dws = (None, None) if xs is not None else (outs[0], outs[2])
             _check(lib.fhvae_gauss_head_bwd_pair(_p(h_lp), K, _p(wt), ldg, _p(g_lp), ldg, _p(colsum), colsum.shape[0] if colsum is not None else 0, _p(dh), K,
                                                  _p(dws[0]), _p(dws[1]),
-                                                 _p(outs[1]), _p(outs[3]), M, K, D, _stream()), "fhvae_gauss_head_bwd_pair")
+                                                 None if db_done else _p(outs[1]), None if db_done else _p(outs[3]), M, K, D, _stream()),
+                   "fhvae_gauss_head_bwd_pair")
             if xs is not None:
                 _DEFER["extra"].extend((x, (g_lp, h_lp, outs[0], outs[2])) for x in xs)
         dw_mu, db_mu, dw_lv, db_lv = (None if k is not None else o for k, o in zip(sk, outs))
-        return dh, None, dw_mu, db_mu, dw_lv, db_lv, None
+        return dh, None, dw_mu, db_mu, dw_lv, db_lv, None, None
 
 
-def gauss_head(h, w_mu, b_mu, w_lv, b_lv, eps, h_lp=None):
-    """h_lp: optional bf16 copy of h -> the contractions run on bf16 MFMA operands (K and D multiples of 8)."""
+def head_shadow_shapes(w_mu):
+    """Shapes of the stacked bf16 operands (wl, wt) of a bf16 head with weights like w_mu [D,K], or None if it takes the f32 path."""
+    D, K = w_mu.shape
+    if K % 8 or D % 8:
+        return None
+    return (2 * D, K), (K, _pair_ld(D))
+
+
+def gauss_head(h, w_mu, b_mu, w_lv, b_lv, eps, h_lp=None, shadows=None):
+    """h_lp: optional bf16 copy of h -> the contractions run on bf16 MFMA operands (K and D multiples of 8).
+    shadows: the head's stacked bf16 weights if something earlier in the step already made them (lstm_seq(head=...))."""
     if h_lp is not None and h.shape[1] % 8 == 0 and w_mu.shape[0] % 8 == 0:
-        mu, lv, smp = _GaussHeadLp.apply(h, h_lp, w_mu, b_mu, w_lv, b_lv, eps)
+        mu, lv, smp = _GaussHeadLp.apply(h, h_lp, w_mu, b_mu, w_lv, b_lv, eps, shadows)
     else:
         mu, lv, smp = _GaussHead.apply(h, w_mu, b_mu, w_lv, b_lv, eps)
     return mu, lv, (smp if eps is not None else None)
@@ -670,9 +693,11 @@ class _LstmSeq(torch.autograd.Function):
     dtype = F32 (exact-f32 MFMA) or BF16 (bf16 MFMA operands, f32 accumulate / cell state)."""
 
     @staticmethod
-    def forward(ctx, x_tm, xc, T, dtype, top, *params):
+    def forward(ctx, x_tm, xc, T, dtype, top, head, *params):
         """top: 2 = f32 top-layer h_t is an output (default); 1 (bf16 only) = the returned f32 tensor only ROUTES the
-        gradient, its values are undefined and the data is its `_fh_lp` bf16 twin; 0 = no per-step output at all (only hn)."""
+        gradient, its values are undefined and the data is its `_fh_lp` bf16 twin; 0 = no per-step output at all (only hn).
+        head: None or (w_mu, w_lv) of the Gaussian head that reads this net's output (bf16 mode): its stacked bf16 operands are
+        made by the forward's operand-cast launch and ride on the outputs as `_fh_head`."""
         lib = load_library()
         ctx.set_materialize_grads(False)  # encoders use only hn, the decoder only hs_top: the other gradient stays None
         _need_gpu(x_tm, xc, *params)
@@ -697,6 +722,7 @@ class _LstmSeq(torch.autograd.Function):
         cs = torch.empty(L, T, B, H, **f32)
         gates = torch.empty(L, T, B, 4 * H, device=dev, dtype=hs.dtype)
         hn = torch.empty(B, L * H, **f32)
+        hn_lp = torch.empty(B, L * H, device=dev, dtype=torch.bfloat16) if bf else None  # the latent head's bf16 operand
         if not bf:
             top = 2
         hs_top = torch.empty(T, B, H, **f32) if (bf and top != 0) else None
@@ -710,6 +736,14 @@ class _LstmSeq(torch.autograd.Function):
             del LSTM_WORKSPACES[:-16]
         d.lp = _p(lp)
         d.hs, d.cs, d.gates, d.hn, d.hs_top_f32, d.lp = _p(hs), _p(cs), _p(gates), _p(hn), _p(hs_top if top == 2 else None), _p(lp)
+        d.hn_lp = _p(hn_lp)
+        shadows = None
+        if bf and head is not None and head_shadow_shapes(head[0]) is not None:
+            hw_mu, hw_lv = _f32c(head[0].detach()), _f32c(head[1].detach())
+            (sl, st_) = head_shadow_shapes(hw_mu)
+            shadows = (torch.empty(sl, device=dev, dtype=torch.bfloat16), torch.empty(st_, device=dev, dtype=torch.bfloat16))
+            d.head_w_mu, d.head_w_lv, d.head_wl, d.head_wt = _p(hw_mu), _p(hw_lv), _p(shadows[0]), _p(shadows[1])
+            d.head_D, d.head_K, d.head_ldt = hw_mu.shape[0], hw_mu.shape[1], st_[1]
         # layer-0 input projection workspace: (T,B,4H) only for the schedules that read it (168 MB per net at B = 2048, H = 256)
         pre = torch.empty(max(1, int(lib.fhvae_lstm_pre_elems(C.byref(d)))), **f32)
         d.pre = _p(pre)
@@ -720,6 +754,9 @@ class _LstmSeq(torch.autograd.Function):
         ctx.x_lp = x_lp
         ctx.layout_id = int(lib.fhvae_lstm_layout_id(C.byref(d)))  # the schedule this forward took (see backward)
         ctx.save_for_backward(x_tm, xc, hs, cs, gates, lp, *params)
+        if hn_lp is not None:
+            hn._fh_lp = hn_lp  # the same values in bf16, written by the forward itself (fhvae_lstm_desc.hn_lp)
+        hn._fh_head = shadows
         if top == 0:
             out = hn.new_empty(())  # placeholder (value never read): this net's per-step states are not an output
             ctx.mark_non_differentiable(out)
@@ -727,6 +764,7 @@ class _LstmSeq(torch.autograd.Function):
         out = hs_top if bf else hs[L - 1]
         if bf:
             out._fh_lp = hs[L - 1]  # the same values in bf16 (what the recurrence itself consumed): operand of a bf16 head
+        out._fh_head = shadows
         return out, hn
 
     @staticmethod
@@ -738,7 +776,7 @@ class _LstmSeq(torch.autograd.Function):
         dev = hs.device
         f32 = dict(device=dev, dtype=torch.float32)
         if d_hs_top is None and d_hn is None:
-            return (None,) * (5 + 4 * L)
+            return (None,) * (6 + 4 * L)
         d_hs_top = _f32c(d_hs_top) if d_hs_top is not None else None
         d_hn = _f32c(d_hn) if d_hn is not None else None
         bd = LstmBwdDesc()
@@ -770,7 +808,7 @@ class _LstmSeq(torch.autograd.Function):
             _DEFER["pending"].append((bd, (x_tm, xc, hs, cs, gates, lp, pre, dgates, dgsum, dc, d_hs_top, d_hn, params, ctx.x_lp)))
             if LSTM_BWD_REC_HOOK["fn"] is not None:  # the distributed runner decides when to flush the queue and start collectives
                 LSTM_BWD_REC_HOOK["fn"](ctx.sinks)
-            return (None, d_xc, None, None, None, *[None] * len(params))
+            return (None, d_xc, None, None, None, None, *[None] * len(params))
         if _SIDE["enabled"] and all(sk is not None for sk in ctx.sinks):
             # recurrence on this stream; the weight-gradient contractions on the side stream, joined by the optimizer
             bd.phase = 1
@@ -798,13 +836,14 @@ class _LstmSeq(torch.autograd.Function):
             bd.phase = 0
             with _Timed("fhvae_lstm_seq_bwd"):
                 _check(lib.fhvae_lstm_seq_bwd(C.byref(bd), _stream()), "fhvae_lstm_seq_bwd")
-        return (None, d_xc, None, None, None, *[None if sk is not None else g for g, sk in zip(grads, ctx.sinks)])
+        return (None, d_xc, None, None, None, None, *[None if sk is not None else g for g, sk in zip(grads, ctx.sinks)])
 
 
-def lstm_seq(x_tm, xc, T, params: Sequence[torch.Tensor], dtype: int = F32, top: int = 2):
+def lstm_seq(x_tm, xc, T, params: Sequence[torch.Tensor], dtype: int = F32, top: int = 2, head=None):
     """top (bf16 only; see _LstmSeq.forward): 2 = f32 top-layer states are written and returned; 1 = the returned f32
-    tensor carries the gradient only (values undefined, data in its `_fh_lp`); 0 = only the final states are wanted."""
-    return _LstmSeq.apply(x_tm, xc, int(T), int(dtype), int(top), *params)
+    tensor carries the gradient only (values undefined, data in its `_fh_lp`); 0 = only the final states are wanted.
+    head: (w_mu, w_lv) of the Gaussian head behind this net, or None (see _LstmSeq.forward)."""
+    return _LstmSeq.apply(x_tm, xc, int(T), int(dtype), int(top), head, *params)
 
 
 def raw_gather_rows(table, idx, idx_offset=0):
@@ -904,6 +943,7 @@ class _Elbo(torch.autograd.Function):
         lib = load_library()
         ts = ctx.saved_tensors
         B, T, F_, xs, xos = ctx.layout
+        _PAIR_GRAD.clear()
         bd = ElboBwdDesc()
         _fill_elbo_desc(bd.f, ts[0], xs, ts[1], ts[2], xos, *ts[3:], ctx.nsegs, B, T, F_)
         gs = [_f32c(g) if g is not None else None for g in (g_lb, g_px, g_k1, g_k2, g_pm)]
@@ -919,7 +959,7 @@ class _Elbo(torch.autograd.Function):
             # time-major rows, whole float4 groups: the kernel also leaves the bf16 operand + column sums for the head's backward
             if PAIR_SIDE["enabled"] and xs == (F_, B * F_) and F_ % 4 == 0 and F_ <= 256 and ts[0].data_ptr() % 16 == 0 and ts[1].data_ptr() % 16 == 0:
                 ldg = _pair_ld(F_)
-                side = (dbuf.data_ptr(), torch.empty(T * B, ldg, device=dbuf.device, dtype=torch.bfloat16),
+                side = (dbuf, torch.empty(T * B, ldg, device=dbuf.device, dtype=torch.bfloat16),
                         torch.empty(int(lib.fhvae_elbo_colsum_rows(B)), 2 * F_, device=dbuf.device, dtype=torch.float32))
                 bd.d_x_pair_lp, bd.ld_pair, bd.d_x_colsum = _p(side[1]), ldg, _p(side[2])
         else:
@@ -931,7 +971,7 @@ class _Elbo(torch.autograd.Function):
         with _Timed("fhvae_elbo_bwd"):
             _check(lib.fhvae_elbo_bwd(C.byref(bd), _stream()), "fhvae_elbo_bwd")
         if side is not None:
-            _PAIR_GRAD["latest"] = side
+            _PAIR_GRAD["latest"] = side + (dbuf._version,)  # (recorded after the kernel call: ctypes writes do not count)
         return (None, d_xmu, d_xlv, *dz, None, None, None)
 
 
@@ -971,9 +1011,10 @@ def fused_loss(lower_bound, log_qy, alpha):
     return _FusedLoss.apply(lower_bound, log_qy, float(alpha))
 
 
-def raw_disc_fwd(q, table, idx, row0=0, want_ce=True, lp=False, out3=None):
+def raw_disc_fwd(q, table, idx, row0=0, want_ce=True, lp=False, out3=None, ce_scale=1.0):
     """lp: the bf16 compute mode's kernels (split-operand bf16 MFMA) where they apply (D = 32, B*S >= 65536).
-    out3: an optional (3, B) f32 buffer that receives (row_max, row_sumexp, tgt_logit) as its rows."""
+    out3: an optional (3, B) f32 buffer that receives (row_max, row_sumexp, tgt_logit) as its rows.
+    ce_scale: the returned scalar is ce_scale * CE (-1: the intended objective's log_qy without a negation launch)."""
     lib = load_library()
     B, D = q.shape
     S = table.shape[0]
@@ -982,22 +1023,26 @@ def raw_disc_fwd(q, table, idx, row0=0, want_ce=True, lp=False, out3=None):
     rmax, rsum, tgt = (out3[0], out3[1], out3[2]) if out3 is not None else (torch.empty(B, device=dev, dtype=torch.float32) for _ in range(3))
     ce = torch.empty((), device=dev, dtype=torch.float32) if want_ce else None
     with _Timed("fhvae_disc_lse_fwd"):
-        _check(lib.fhvae_disc_lse_fwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(tgt), _p(ce), _p(ws),
-                                      B, S, D, BF16 if lp else F32, _stream()), "fhvae_disc_lse_fwd")
+        _check(lib.fhvae_disc_lse_fwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(tgt), _p(ce), float(ce_scale),
+                                      _p(ws), B, S, D, BF16 if lp else F32, _stream()), "fhvae_disc_lse_fwd")
     return rmax, rsum, tgt, ce
 
 
-def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True, need_dt=True, dt_sink=None, lp=False):
+def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True, need_dt=True, dt_sink=None, lp=False, ws_bytes=None):
+    """ws_bytes: size of the one-pass form's workspace (default: the library's recommendation, capped at 1.5 GiB; a smaller
+    workspace makes the kernels take the queries in groups; 0 = two passes)."""
     lib = load_library()
     B, D = q.shape
     S = table.shape[0]
     dq = torch.empty(B, D, device=q.device, dtype=torch.float32) if need_dq else None
     dt = dt_sink if dt_sink is not None else (torch.zeros(S, D, device=q.device, dtype=torch.float32) if need_dt else None)
     # workspace of the one-pass form (both gradients from one recomputation of the logits)
-    ws = torch.empty(max(int(lib.fhvae_disc_lse_bwd_ws_bytes(B, S, D)), 8), device=q.device, dtype=torch.uint8) if (need_dq and dt is not None) else None
+    nws = int(lib.fhvae_disc_lse_bwd_ws_bytes(B, S, D)) if ws_bytes is None else int(ws_bytes)
+    ws = torch.empty(nws, device=q.device, dtype=torch.uint8) if (need_dq and dt is not None and nws > 0) else None
     with _Timed("fhvae_disc_lse_bwd"):
         _check(lib.fhvae_disc_lse_bwd(_p(q), _p(table), _p(idx), row0, INV_TWO_VAR, _p(rmax), _p(rsum), _p(g_scale), float(g_mul),
-                                      _p(dq), _p(dt), _p(ws), B, S, D, BF16 if lp else F32, _stream()), "fhvae_disc_lse_bwd")
+                                      _p(dq), _p(dt), _p(ws), nws if ws is not None else 0, B, S, D, BF16 if lp else F32, _stream()),
+               "fhvae_disc_lse_bwd")
     return dq, (None if dt_sink is not None else dt)
 
 
@@ -1047,11 +1092,11 @@ def shard_bwd_unpack(buf, own0, n_own, want_dq=True, want_dmu2=True):
     return dq, dm
 
 
-def raw_disc_ce_mean(m, s, tgt):
+def raw_disc_ce_mean(m, s, tgt, scale=1.0):
     lib = load_library()
     ce = torch.empty((), device=m.device, dtype=torch.float32)
     with _Timed("fhvae_disc_ce_mean"):
-        _check(lib.fhvae_disc_ce_mean(_p(m), _p(s), _p(tgt), _p(ce), m.numel(), _stream()), "fhvae_disc_ce_mean")
+        _check(lib.fhvae_disc_ce_mean(_p(m), _p(s), _p(tgt), _p(ce), float(scale), m.numel(), _stream()), "fhvae_disc_ce_mean")
     return ce
 
 
@@ -1060,12 +1105,13 @@ class _DiscLse(torch.autograd.Function):
     simple_fhvae.py:119-122, without the (B,S,D) temporaries."""
 
     @staticmethod
-    def forward(ctx, q, table, idx, lp):
+    def forward(ctx, q, table, idx, lp, sign):
         _need_gpu(q, table, idx)
         ctx.sink = _sink(table)
         ctx.lp = bool(lp)
+        ctx.sign = float(sign)
         q, table = _f32c(q), _f32c(table)
-        rmax, rsum, _, ce = raw_disc_fwd(q, table, idx, lp=ctx.lp)
+        rmax, rsum, _, ce = raw_disc_fwd(q, table, idx, lp=ctx.lp, ce_scale=ctx.sign)
         ctx.save_for_backward(q, table, idx, rmax, rsum)
         return ce
 
@@ -1073,14 +1119,15 @@ class _DiscLse(torch.autograd.Function):
     def backward(ctx, g):
         q, table, idx, rmax, rsum = ctx.saved_tensors
         g = _f32c(g).reshape(1)
-        dq, dt = raw_disc_bwd(q, table, idx, rmax, rsum, g, 1.0 / q.shape[0], need_dq=ctx.needs_input_grad[0],
+        dq, dt = raw_disc_bwd(q, table, idx, rmax, rsum, g, ctx.sign / q.shape[0], need_dq=ctx.needs_input_grad[0],
                               need_dt=ctx.needs_input_grad[1], dt_sink=ctx.sink, lp=ctx.lp)
-        return dq, dt, None, None
+        return dq, dt, None, None, None
 
 
-def disc_lse(q, table, idx, lp=False):
-    """lp=True: the bf16 compute mode (models built with compute_dtype='bf16'); default = the f32 parity mode."""
-    return _DiscLse.apply(q, table, idx, bool(lp))
+def disc_lse(q, table, idx, lp=False, sign=1.0):
+    """lp=True: the bf16 compute mode (models built with compute_dtype='bf16'); default = the f32 parity mode.
+    sign: the result is sign * CE (the reference returns +CE as log_qy, simple_fhvae.py:122; the intended objective -CE)."""
+    return _DiscLse.apply(q, table, idx, bool(lp), float(sign))
 
 
 def wgrad_bf16_(c, a, b):

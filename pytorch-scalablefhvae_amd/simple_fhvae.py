@@ -61,12 +61,16 @@ class GaussianLayer(nn.Module):
         self.mulayer = nn.Linear(input_size, dim)
         self.logvar_layer = nn.Linear(input_size, dim)
 
-    def forward(self, input_layer: torch.Tensor, eps=None, sample=True, input_lp=None):
-        """input_lp: optional bf16 copy of input_layer (compute_dtype='bf16' models): bf16 MFMA operands."""
+    def forward(self, input_layer: torch.Tensor, eps=None, sample=True, input_lp=None, shadows=None):
+        """input_lp: optional bf16 copy of input_layer (compute_dtype='bf16' models): bf16 MFMA operands; shadows: the stacked
+        bf16 copies of this layer's weights if the net in front of it already made them this step (hip_binding.lstm_seq)."""
         if sample and eps is None:
             eps = torch.randn(input_layer.shape[0], self.mulayer.out_features, device=input_layer.device)
         return hb.gauss_head(input_layer, self.mulayer.weight, self.mulayer.bias, self.logvar_layer.weight,
-                             self.logvar_layer.bias, eps if sample else None, h_lp=input_lp)
+                             self.logvar_layer.bias, eps if sample else None, h_lp=input_lp, shadows=shadows)
+
+    def head_weights(self):
+        return self.mulayer.weight, self.logvar_layer.weight
 
 
 class PreDecoder(nn.Module):

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), "libfhvae_hip.so lacks %s" % n
         assert n in hb.SIGNATURES, "hip_binding does not bind %s" % n
     assert set(hb.SIGNATURES) == set(names)
-    assert lib.fhvae_abi_version() == 9
+    assert lib.fhvae_abi_version() == 10
     assert lib.fhvae_strerror(-1) == b"required pointer is NULL"
 
 
@@ -44,7 +44,7 @@ def test_struct_layouts_match_header(lib):
     import hip_binding as hb
 
     # sizes computed from the header by hand: pointers/int64 are 8 bytes, int32 pairs packed
-    assert ctypes.sizeof(hb.LstmDesc) == 8 + 5 * 8 + 3 * 8 + 4 * 4 * 8 + 8 * 8
+    assert ctypes.sizeof(hb.LstmDesc) == 8 + 5 * 8 + 3 * 8 + 4 * 4 * 8 + 8 * 8 + 8 + 7 * 8   # + hn_lp + the head_* fields (ABI 10)
     assert ctypes.sizeof(hb.LstmBwdDesc) == ctypes.sizeof(hb.LstmDesc) + 5 * 8 + 4 * 4 * 8 + 8 + 8 + 8
     assert ctypes.sizeof(hb.ElboDesc) == 5 * 8 + 3 * 8 + 4 * 8 + 5 * 8 + 2 * 8 + 5 * 8
     assert ctypes.sizeof(hb.ElboBwdDesc) == ctypes.sizeof(hb.ElboDesc) + 5 * 8 + 8 + 7 * 8 + 3 * 8
@@ -71,10 +71,26 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     assert lib.fhvae_wgrad_f32(p, 6, p, 8, p, 8, 4, 8, 16, None) == -4                   # lda = 6 is not a multiple of 4
     assert lib.fhvae_head_pair_weights(p, p, p, p, 8, 8, 16, None) == -2                 # ldt = 8 < 2D = 16
     assert lib.fhvae_gauss_head_bwd_pair(None, 64, None, 64, None, 64, None, 0, None, 64, None, None, None, None, 8, 64, 8, None) == -1
-    assert lib.fhvae_gauss_reparam_bwd_pair(None, None, p, None, None, 8, p, 16, 4, 8, None) == -1   # d_sample without eps / logvar
+    assert lib.fhvae_gauss_reparam_bwd_pair(None, None, p, None, None, 8, p, 16, None, None, 4, 8, None) == -1   # d_sample without eps / logvar
     w = hb.WgradDesc(None, 8, 0, None, 8, None, 8, 8, 8, 64)
     assert lib.fhvae_wgrad_desc_ok(ctypes.byref(w)) == 0
     assert lib.fhvae_disc_lse_bwd_ws_bytes(2048, 28000, 32) > 0 and lib.fhvae_disc_lse_bwd_ws_bytes(8, 8, 32) == 0
+    # ABI 10: the one-pass K5 backward's workspace is capped (the whole problem up to 1.5 GiB, then query groups): c5 and a
+    # rank's view of the 8-GPU shapes fit whole, 16384 queries against 10^6 rows do not
+    cap = 3 << 29
+    assert lib.fhvae_disc_lse_bwd_ws_bytes(2048, 1000000, 32) == (64 * 2048 * 32 + 8 * 1000000 * 33) * 4
+    assert lib.fhvae_disc_lse_bwd_ws_bytes(16384, 125000, 32) <= cap
+    big = lib.fhvae_disc_lse_bwd_ws_bytes(16384, 1000000, 32)
+    assert 0 < big <= cap and big >= 1000000 * 33 * 4
+    assert lib.fhvae_disc_lse_bwd_ws_bytes(65536, 1000000, 32) <= cap
+    # a head's stacked operands in the forward's operand-cast launch: bf16 mode only, both weights, a destination
+    d = hb.LstmDesc()
+    d.L, d.B, d.T, d.H, d.I, d.dtype = 1, 8, 2, 8, 8, hb.F32
+    for k in ("x", "hs", "cs", "gates", "pre", "head_w_mu"):
+        setattr(d, k, p.value)
+    for k in ("w_ih", "w_hh", "b_ih", "b_hh"):
+        getattr(d, k)[0] = p.value
+    assert lib.fhvae_lstm_seq_fwd(ctypes.byref(d), None) == -3
     assert lib.fhvae_elbo_colsum_rows(2048) == 1024
 
 

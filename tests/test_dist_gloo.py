@@ -63,8 +63,8 @@ class OracleBackend:
         D = buf.shape[1] // 2
         return (buf[own0:own0 + n_own, :D].contiguous() if want_dq else None), (buf[:, D:].contiguous() if want_dmu2 else None)
 
-    def ce_mean(self, m, s, tgt):
-        return ((m - tgt) + torch.log(s)).mean()
+    def ce_mean(self, m, s, tgt, scale=1.0):
+        return scale * ((m - tgt) + torch.log(s)).mean()
 
     def disc_bwd(self, q_all, shard, idx_all, row0, m, s, g, g_mul, need_dq, need_dt):
         t = shard.detach()

@@ -207,3 +207,29 @@ def test_switch_parity_smoke(hb, name, value, shape, extra):
         assert (gu - gv).abs().max().item() < 2e-2 * scale, (name, n, (gu - gv).abs().max().item(), scale)
     if Ic:
         assert (a[3] - b[3]).abs().max().item() < 2e-2 * (a[3].abs().max().item() + 1e-30), (name, "d_xc")
+
+
+def test_forward_leaves_the_heads_bf16_operands(hb):
+    """ABI 10: a bf16 forward also writes hn in bf16 (fhvae_lstm_desc.hn_lp; fused into lstm_fwd_wr.hip's final-state stores, a
+    cast at the end of the other schedules) and, given the Gaussian head behind the net, the head's stacked bf16 weights from
+    its operand-cast launch (fhvae_lstm_desc.head_*) -- bit for bit what the separate launches produced."""
+    import ctypes as C
+
+    lib = hb.load_library()
+    for B, H, L, Dh in ((2048, 256, 2, 32), (256, 256, 2, 32), (192, 128, 1, 80)):  # wr forward / k-split cluster / generic
+        torch.manual_seed(B + H)
+        T, I = 5, 80
+        lstm = torch.nn.LSTM(I, H, L)
+        names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        params = [getattr(lstm, n).detach().cuda() for n in names]
+        K = L * H
+        w_mu, w_lv = torch.randn(Dh, K).cuda(), torch.randn(Dh, K).cuda()
+        hs, hn = hb.lstm_seq(torch.randn(T, B, I).cuda(), None, T, params, hb.BF16, head=(w_mu, w_lv))
+        assert hb.lstm_sync_status() == 0
+        assert torch.equal(hn._fh_lp, hn.to(torch.bfloat16))
+        wl, wt = hn._fh_head
+        ldt = wt.shape[1]
+        rl, rt = torch.empty_like(wl), torch.empty_like(wt)
+        assert lib.fhvae_head_pair_weights(w_mu.data_ptr(), w_lv.data_ptr(), rl.data_ptr(), rt.data_ptr(), ldt, Dh, K,
+                                           torch.cuda.current_stream().cuda_stream) == 0
+        assert torch.equal(wl, rl) and torch.equal(wt, rt) and ldt >= 2 * Dh and (ldt == 2 * Dh or float(wt[:, 2 * Dh:].abs().sum()) == 0.0)

@@ -552,3 +552,26 @@ def test_lstm_workspace_size_queries(hb):
     assert n == 16384 + 4 * (3 * 4 * 256 * 256) and lib.fhvae_lstm_pre_elems(C.byref(d)) == T * 64 * 4 * 256
     d, n, keep = desc(hb.F32, 2, 64, T, 0, 64, 256)  # time-constant input only: one (B,4H) slab
     assert lib.fhvae_lstm_pre_elems(C.byref(d)) == 64 * 4 * 256
+
+
+@pytest.mark.parametrize("M,D", [(2048, 32), (100, 32), (40960, 80), (7, 8)])
+def test_reparam_bwd_pair_bias_sums_ride_along(hb, M, D):
+    """ABI 10: fhvae_gauss_reparam_bwd_pair adds the two bias gradients (column sums of the bf16 operand it writes) in the same
+    launch where a workgroup covers whole rows (ldg/8 divides 256), and through the column-sum kernel otherwise."""
+    lib = hb.load_library()
+    g = torch.Generator().manual_seed(M + D)
+    d_mu, d_lv, d_s, eps = (torch.randn(M, D, generator=g).cuda() for _ in range(4))
+    lv = (torch.randn(M, D, generator=g) * 0.3).cuda()
+    ldg = (2 * D + 63) // 64 * 64
+    g_lp = torch.empty(M, ldg, device="cuda", dtype=torch.bfloat16)
+    db_mu, db_lv = torch.full((D,), 0.5, device="cuda"), torch.full((D,), -0.25, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.fhvae_gauss_reparam_bwd_pair(d_mu.data_ptr(), d_lv.data_ptr(), d_s.data_ptr(), eps.data_ptr(), lv.data_ptr(), D,
+                                            g_lp.data_ptr(), ldg, db_mu.data_ptr(), db_lv.data_ptr(), M, D, st) == 0
+    want_mu = d_mu + d_s
+    want_lv = d_lv + d_s * eps * 0.5 * torch.exp(0.5 * lv)
+    close(g_lp[:, :D].float(), want_mu, rtol=1e-2, what="g_mu (bf16)")
+    close(g_lp[:, D:2 * D].float(), want_lv, rtol=1e-2, what="g_lv (bf16)")
+    assert float(g_lp[:, 2 * D:].float().abs().sum()) == 0.0
+    close(db_mu - 0.5, g_lp[:, :D].double().sum(0).float(), rtol=1e-5, what="db_mu += column sums")
+    close(db_lv + 0.25, g_lp[:, D:2 * D].double().sum(0).float(), rtol=1e-5, what="db_lv += column sums")
