@@ -11,8 +11,12 @@ passes the one JSON line of rank 0 through.
 A "step" = zero_grad -> forward -> loss_function -> backward -> Adam over one synthetic (B,20,80) batch
 already resident in HBM (train_model.py:446-454).  Workload at N=1: BASELINE.json configs[2], the largest
 single-GPU configuration (fhvae.FHVAE 2x256 LSTM enc/dec, z1=z2=32, 28k-row mu2 table, batch 2048, bf16);
-configs[1] (4.6k-row table) at batch 2048 and at the reference's default training batch 256 is reported beside
-it as `alt`.  value = segments/s over all ranks.
+configs[1] (4.6k-row table) at batch 2048 and at the reference's default training batch 256, and the headline workload in the
+exact-f32 parity mode, are reported beside it as `alt`.  value = segments/s over all ranks.
+N > 1: DP over the minibatch + the row-sharded mu2 table (dist_shard.py); beside the c3 headline the `alt` list carries
+configs[3] (2x512, 100k rows) and configs[4] (1M rows, T = 40, fp32) -- the workloads north_star's 8-GPU targets are quoted on.
+The distributed step is measured EAGERLY first and then as a captured hipGraph; a watchdog prints the eager record and ends the
+ranks if the captured form (RCCL collectives inside a graph, never run at N > 1 before the first hardware run) does not come back.
 Objective: the intended one (decoder attached, log_qy=-CE): the reference's literal `.detach()`
 objective would skip the whole decoder backward, i.e. less work in the timed region.
 """
@@ -41,23 +45,103 @@ CONFIGS = {
     "c4": dict(H=512, L=2, D=32, S=100000, T=20, F=80, B=2048, desc="2x512 LSTM, 100k-seq mu2 table"),
     "c5": dict(H=256, L=2, D=32, S=1000000, T=40, F=80, B=2048, dtype="f32", desc="1M-seq mu2 table, 40-frame segments, fp32"),
 }
-#: what the default (no --config) run reports beside the headline: (config, per-GPU batch)
-ALT_RUNS = [("c2", 2048), ("c2", 256)]
+#: what the default (no --config) run reports beside the headline: (config, per-GPU batch, dtype or None = the config's)
+ALT_RUNS = [("c2", 2048, None), ("c2", 256, None), ("c3", 2048, "f32")]
+#: ... and with N > 1 ranks (row-sharded tables: the configurations north_star's multi-GPU targets name)
+ALT_RUNS_DIST = [("c4", 2048, None), ("c5", 2048, None)]
 
 
 def self_launch(args, argv):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the ranks as a child process tree.  Nothing in
-    this process has initialised HIP (no torch.cuda call, no library load): the child processes own the GPUs."""
+    this process has initialised HIP (no torch.cuda call, no library load): the child processes own the GPUs.  The tree runs
+    under a time limit (--launch-timeout); when it expires the whole process group is killed and ONE fresh tree is started with
+    --no-dist-graph --no-alt (never a re-exec of a process that touched the GPU); the record's `launch` field says so."""
+    import signal
     import socket
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    def run(extra, env_extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv + extra
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(env_extra)
+        proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+        try:
+            return proc.wait(timeout=args.launch_timeout if args.launch_timeout > 0 else None)
+        except subprocess.TimeoutExpired:
+            # the launcher puts its workers into sessions of their own: collect the exact descendants of the tree started above
+            # (never a pattern match), then end the launcher's group and every one of them
+            pids = []
+            try:
+                import psutil
+
+                pids = [c.pid for c in psutil.Process(proc.pid).children(recursive=True)]
+            except Exception:  # noqa: BLE001
+                pass
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            for pid in pids:
+                try:
+                    os.kill(pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+            proc.wait()
+            return None
+
+    rc = run([], {})
+    if rc is None:
+        print("bench: the %d-rank run did not finish within %d s; starting a fresh one with --no-dist-graph --no-alt"
+              % (args.gpus, args.launch_timeout), file=sys.stderr)
+        rc = run(["--no-dist-graph", "--no-alt"], {"FHVAE_BENCH_RETRY": "1"})
+        if rc is None:
+            print("bench: the second attempt did not finish either", file=sys.stderr)
+            rc = 124
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# watchdog of the multi-rank run: a phase that does not come back (the first captured replay of a step with RCCL collectives
+# in it is the candidate) must not lose what was already measured.  One daemon thread per rank; when the armed deadline passes,
+# rank 0 prints the record prepared so far (the eager measurement) and every rank ends with os._exit (the main thread is stuck
+# inside a HIP / RCCL call: nothing else can end it).
+# ---------------------------------------------------------------------------------------------
+WATCHDOG = {"deadline": None, "emit": None, "what": "", "started": False}
+
+
+def watchdog_arm(seconds, what):
+    import threading
+
+    WATCHDOG["deadline"], WATCHDOG["what"] = (time.time() + seconds if seconds else None), what
+    if WATCHDOG["started"] or not seconds:
+        return
+
+    def loop():
+        while True:
+            time.sleep(1.0)
+            d = WATCHDOG["deadline"]
+            if d is not None and time.time() > d:
+                print("bench: watchdog: '%s' did not finish in time; ending this rank" % WATCHDOG["what"], file=sys.stderr)
+                code = 3
+                if WATCHDOG["emit"] is not None:
+                    try:
+                        WATCHDOG["emit"](WATCHDOG["what"])
+                        code = 0
+                    except Exception as exc:  # noqa: BLE001
+                        print("bench: watchdog could not emit the record: %s" % exc, file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(code)
+
+    WATCHDOG["started"] = True
+    threading.Thread(target=loop, daemon=True).start()
+
+
+def watchdog_disarm():
+    WATCHDOG["deadline"] = None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -303,7 +387,10 @@ def cpu_baseline(cfg, dtype, budget_s=45.0, sample_B=256):
 # ---------------------------------------------------------------------------------------------
 # one GPU measurement
 # ---------------------------------------------------------------------------------------------
-def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no_graph, want_roofline, idx_dist, dist_graph=False):
+def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no_graph, want_roofline, idx_dist, dist_graph=False,
+            on_eager=None):
+    """on_eager(result): called with the EAGER measurement of a distributed step before its capture into a hipGraph is
+    attempted (main arms the watchdog with it)."""
     import torch
 
     import hip_binding as hb
@@ -354,6 +441,30 @@ def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no
     # too (collectives are graph-capturable; --no-dist-graph runs it eagerly).
     use_graph = (not no_graph) and (runner is None or dist_graph)
     step = eager_step
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, lb = fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        return dt, loss, lb
+
+    eager = None
+    if use_graph and runner is not None and world > 1:
+        # the multi-rank step, eagerly, FIRST: a valid measurement exists before the captured form is tried
+        dt, loss, lb = timed(eager_step)
+        eager = {"value": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "elbo_nats_per_frame": (lb.mean() / T).item(),
+                 "loss_finite": bool(torch.isfinite(loss).item()), "launch": "eager", "dtype": dtype, "batch": B}
+        if on_eager is not None:
+            on_eager(eager)
     if use_graph:
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)  # capture runs on a side stream by design
         side = torch.cuda.Stream()
@@ -378,24 +489,17 @@ def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no
                 graph.replay()
                 return g_loss, g_lb
 
-    for _ in range(warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss, lb = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    dt, loss, lb = timed(step)
     elbo = (lb.mean() / T).item()
     ok = bool(torch.isfinite(loss).item())
     if hb.lstm_sync_status() != 0:
         raise SystemExit("a persistent LSTM recurrence launch gave up (status %d): results invalid" % hb.lstm_sync_status())
     res = {"value": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "elbo_nats_per_frame": elbo, "loss_finite": ok,
            "launch": "hipGraph replay of the whole step" if use_graph else "eager", "dtype": dtype, "batch": B}
+    if eager is not None:
+        res["eager"] = {"value": eager["value"], "ms_per_step": eager["ms_per_step"]}
+    if os.environ.get("FHVAE_BENCH_RETRY"):
+        res["launch"] += " (second attempt: the first %d-rank run did not finish within --launch-timeout)" % world
 
     if want_roofline:  # every rank runs the instrumented steps (they contain collectives); rank 0 reports
         # Instrumented EAGER repeat of the same steps: (1) HIP events (torch's current stream == the launch stream)
@@ -430,8 +534,22 @@ def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no
                 traffic = json.load(open(tf)).get("%s_%s_B%d" % (names[dom], dtype, B))
             except Exception:
                 traffic = None
+        hbm_frac = None
+        if traffic:  # counter bytes of that kernel / its live average duration / 8 TB/s: how near the HBM roof the kernel is
+            traffic = dict(traffic, source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, replayed here: "
+                                           "not measured in this run)")
+            hbm_frac = traffic["hbm_bytes_per_launch"] / (t_ms / n * 1e-3) / 8e12
+        cell_hbm = {}
+        try:
+            tj = json.load(open(tf)) if os.path.exists(tf) else {}
+            for k, v in cells.items():
+                e = tj.get("%s_%s_B%d" % (names[k], dtype, B))
+                if e:
+                    cell_hbm[names[k]] = e["hbm_bytes_per_launch"] / (v[1] / v[0] * 1e-3) / 8e12
+        except Exception:
+            cell_hbm = {}
         res["roofline"] = {"bound": "mfma", "kernel": "%s<%s>" % (names[dom], dtype), "achieved": ach, "peak": peak,
-                           "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                           "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "hbm_frac": hbm_frac, "hbm_frac_by_kernel": cell_hbm,
                            "schedule": hb.LSTM_FORMS[form], "launches_per_step": n / steps, "avg_launch_us": t_ms / n * 1e3,
                            "flops_per_launch": fl / n,
                            "cells": {names[k]: {"launches_per_step": v[0] / steps, "avg_launch_us": v[1] / v[0] * 1e3,
@@ -469,10 +587,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true")
+    ap.add_argument("--launch-timeout", type=int, default=1500,
+                    help="self-launched N > 1 run: seconds before the rank tree is killed and ONE fresh tree is started with "
+                         "--no-dist-graph --no-alt (0 = no limit)")
+    ap.add_argument("--phase-timeout", type=int, default=240,
+                    help="N > 1: seconds a captured (hipGraph) phase may take before the watchdog prints the eager record and ends "
+                         "the ranks (0 = no watchdog)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
+    if os.environ.get("FHVAE_BENCH_TEST_SLEEP"):  # tests/test_bench_cpu.py: a rank that never comes back (before anything touches a GPU)
+        time.sleep(float(os.environ["FHVAE_BENCH_TEST_SLEEP"]))
     if os.environ.get("FHVAE_BENCH_WATCHDOG"):  # diagnostics: dump every thread's Python stack and exit if the run takes longer
         import faulthandler
 
@@ -510,41 +636,78 @@ def main():
     dtype = "f32" if cfg.get("simple") else (args.dtype or cfg.get("dtype", "bf16"))
     B = args.batch or cfg["B"]
     T, F = cfg["T"], cfg["F"]
-    main_res = run_gpu(cfg_name, B, dtype, args.steps, args.warmup, device, rank, world, use_dist, args.no_graph,
-                       not args.no_roofline, args.idx, use_dist and not args.no_dist_graph)
+    state = {"main": None, "alts": []}
 
-    alts = []
-    if default_run and world == 1 and not use_dist and not args.batch and not args.no_alt:
-        for name, b in ALT_RUNS:  # configs[1] at both reference batch sizes, same method as the headline (graph replay)
-            r = run_gpu(name, b, args.dtype or CONFIGS[name].get("dtype", "bf16"), args.steps, 3, device, rank, world, False,
-                        args.no_graph, False, args.idx)
-            alts.append({"workload": "%s: %s; per-GPU batch %d" % (name, CONFIGS[name]["desc"], b), "value": r["value"],
-                         "unit": "segments/s", "ms_per_step": r["ms_per_step"], "launch": r["launch"],
-                         "elbo_nats_per_frame": r["elbo_nats_per_frame"], "dtype": r["dtype"]})
-
-    if rank == 0:
+    def build_record(main_res, note=None):
         rec = {
             "metric": "segments/sec + ELBO (nats/frame), (B,20,80) fbank", "value": main_res["value"],
             "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": main_res["dtype"], "data": "synthetic", "elbo_nats_per_frame": main_res["elbo_nats_per_frame"],
-            "loss_finite": main_res["loss_finite"], "launch": main_res["launch"],
+            "loss_finite": main_res["loss_finite"], "launch": main_res["launch"] + (" -- " + note if note else ""),
             "config": {"workload": "%s: %s; per-GPU batch %d, T=%d, F=%d, full train step (fwd+loss+bwd+Adam), "
                                    "intended objective, mu_idx %s" % (cfg_name, cfg["desc"], B, T, F, args.idx),
                        "global_batch": world * B, "parallelism": "dp%d+mu2-row-shard" % world if use_dist else "single"},
         }
-        for k in ("roofline", "idx"):
+        for k in ("roofline", "idx", "eager"):
             if k in main_res:
                 rec[k] = main_res[k]
+        if state["alts"]:
+            rec["alt"] = list(state["alts"])
+        return rec
+
+    def emit(rec):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+
+    def watchdog_emit(what):  # (watchdog thread) the best record there is: the finished headline, else its eager measurement
+        if rank == 0 and state["main"] is not None:
+            emit(build_record(state["main"], "watchdog: '%s' did not finish within %d s; this record is what had been measured before it"
+                              % (what, args.phase_timeout)))
+
+    guard = world > 1 and args.phase_timeout > 0
+    if guard:
+        WATCHDOG["emit"] = watchdog_emit
+
+    def on_eager_main(e):
+        state["main"] = e
+        if guard:
+            watchdog_arm(args.phase_timeout, "hipGraph capture + replay of the %s step" % cfg_name)
+
+    main_res = run_gpu(cfg_name, B, dtype, args.steps, args.warmup, device, rank, world, use_dist, args.no_graph,
+                       not args.no_roofline, args.idx, use_dist and not args.no_dist_graph, on_eager=on_eager_main)
+    watchdog_disarm()
+    state["main"] = main_res
+
+    def alt_entry(name, b, r):
+        return {"workload": "%s: %s; per-GPU batch %d" % (name, CONFIGS[name]["desc"], b), "value": r["value"],
+                "unit": "segments/s", "ms_per_step": r["ms_per_step"], "launch": r["launch"],
+                "elbo_nats_per_frame": r["elbo_nats_per_frame"], "dtype": r["dtype"], **({"eager": r["eager"]} if "eager" in r else {})}
+
+    if default_run and world == 1 and not use_dist and not args.batch and not args.no_alt:
+        for name, b, dt_alt in ALT_RUNS:  # configs[1] at both reference batch sizes and the headline in f32: same method (graph replay)
+            r = run_gpu(name, b, dt_alt or args.dtype or CONFIGS[name].get("dtype", "bf16"), args.steps, 3, device, rank, world, False,
+                        args.no_graph, False, args.idx)
+            state["alts"].append(alt_entry(name, b, r))
+    if default_run and world > 1 and not args.batch and not args.no_alt:
+        # the configurations the 8-GPU targets are quoted on (row-sharded 100k / 1M-row tables), same method as the headline;
+        # every rank runs them (they contain collectives); a phase that hangs ends the run with what is already measured
+        for name, b, dt_alt in ALT_RUNS_DIST:
+            if guard:
+                watchdog_arm(3 * args.phase_timeout, "alt run %s" % name)
+            r = run_gpu(name, b, dt_alt or CONFIGS[name].get("dtype", "bf16"), max(5, args.steps // 2), 3, device, rank, world, True,
+                        args.no_graph, False, args.idx, not args.no_dist_graph)
+            watchdog_disarm()
+            state["alts"].append(alt_entry(name, b, r))
+
+    if rank == 0:
+        rec = build_record(main_res)
         if "roofline" in rec and world == 1 and default_run and not args.no_hbm:
             # the HBM-bound kernels of the path beside the MFMA-bound dominant one (~2 s, 5 GB of scratch tensors)
             rec["roofline"]["hbm"] = {"peak_gbps": 8000.0, "kernels": hbm_record(device)}
-        if alts:
-            rec["alt"] = alts
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(cfg, main_res["dtype"])
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        emit(rec)
     if use_dist:
         import torch.distributed as dist
 

@@ -295,6 +295,14 @@ class DistributedFHVAE:
                 h = self.sh.all_reduce_(self.opt_nets.g_arena.flat[b:e], async_op=True)
                 self._pending = h if h is not None else False  # None: the transport was synchronous (staged gloo)
 
+    def _drop_stale_pending(self):
+        """An early all-reduce left over from a step whose backward raised after it was issued: wait it out and forget it, or the
+        next step would skip its own early all-reduce (the hook returns while a handle is pending) and reduce only the last
+        bucket -- the ranks would silently diverge."""
+        if self._pending not in (None, False):
+            self._pending.wait()
+        self._pending = None
+
     def _reduce_gradients(self):
         flat = self.opt_nets.flat_grad()  # flushes the weight gradients still queued (the last net's: the second grouped launch)
         if not self._buckets:
@@ -384,11 +392,7 @@ class DistributedFHVAE:
 
         import hip_binding as hb
 
-        # an early all-reduce left over from a step whose backward raised after it was issued: wait it out and forget it, or this
-        # step would skip its own early all-reduce and reduce only the last bucket
-        if self._pending not in (None, False):
-            self._pending.wait()
-        self._pending = None
+        self._drop_stale_pending()
         self.opt_nets.zero_grad()
         self.opt_table.zero_grad()
         out = self.model(x, idx, self.sh.S, nsegs)
