@@ -162,12 +162,15 @@ class _ShardTable(torch.autograd.Function):
         be = sh.backend
         ctx.sign = float(sign)
         # (1) one buffer: the queries and, in the last column, the row indices as int32 bit patterns
-        q_all, idx_all = be.unpack(sh.all_gather(be.pack(q_local, idx_local)))
+        if sh.solo:  # one rank: the exchange is the identity -- no pack / unpack / merge launches either (like the collectives)
+            q_all, idx_all = q_local.detach().float().contiguous(), idx_local.contiguous()
+        else:
+            q_all, idx_all = be.unpack(sh.all_gather(be.pack(q_local, idx_local)))
         # (2) rows: zeros for rows owned elsewhere, so the sum over ranks is the row
         mu2 = sh.reduce_scatter(be.gather_rows(shard, idx_all, sh.row0))
         # (3) K5 partials of this shard for ALL queries, merged locally (an empty shard's (-inf, 0) contributes nothing)
         parts = sh.all_gather(be.disc_partials(q_all, shard, idx_all, sh.row0)).view(sh.world, 3, -1)
-        m, s, t = be.merge_partials(parts)
+        m, s, t = (parts[0, 0], parts[0, 1], parts[0, 2]) if sh.solo else be.merge_partials(parts)
         ce = be.ce_mean(m, s, t, ctx.sign)  # sign * CE (fhvae_core.FHVAEBase._tail)
         ctx.sh, ctx.shape = sh, tuple(shard.shape)
         ctx.sink = getattr(shard, "_fh_grad", None)
@@ -188,9 +191,13 @@ class _ShardTable(torch.autograd.Function):
             # scanned); the query side is averaged over ranks with the net gradients afterwards, so it carries W/B_global
             dq_all, dshard = be.disc_bwd(q_all, shard, idx_all, sh.row0, m, s, g.reshape(1).contiguous(), ctx.sign / n_all, need_dq, need_dt)
         # (4) [dq for all queries | dmu2 of the local queries in their rows], summed over the ranks
-        buf = be.bwd_pack(dq_all, float(sh.world), dmu2, sh.rank * n_loc, n_all, D)
-        sh.all_reduce_(buf)
-        dq_local, dmu2_all = be.bwd_unpack(buf, sh.rank * n_loc, n_loc, need_dq, need_dt)
+        if sh.solo:  # one rank: both halves are already what the unpack would return
+            dq_local = dq_all if need_dq else None
+            dmu2_all = dmu2.contiguous() if (need_dt and dmu2 is not None) else (torch.zeros_like(q_all) if need_dt else None)
+        else:
+            buf = be.bwd_pack(dq_all, float(sh.world), dmu2, sh.rank * n_loc, n_all, D)
+            sh.all_reduce_(buf)
+            dq_local, dmu2_all = be.bwd_unpack(buf, sh.rank * n_loc, n_loc, need_dq, need_dt)
         if need_dt:
             sink = ctx.sink
             if sink is None:
