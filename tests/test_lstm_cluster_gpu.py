@@ -233,3 +233,35 @@ def test_forward_leaves_the_heads_bf16_operands(hb):
         assert lib.fhvae_head_pair_weights(w_mu.data_ptr(), w_lv.data_ptr(), rl.data_ptr(), rt.data_ptr(), ldt, Dh, K,
                                            torch.cuda.current_stream().cuda_stream) == 0
         assert torch.equal(wl, rl) and torch.equal(wt, rt) and ldt >= 2 * Dh and (ldt == 2 * Dh or float(wt[:, 2 * Dh:].abs().sum()) == 0.0)
+
+
+@pytest.mark.parametrize("B,Ic", [(2048, 0), (1024, 32)])
+def test_wr_forward_rs_backward_vs_f32_lstm_mean_error(hb, B, Ic):
+    """The register-stationary forward + partial-dh backward (bf16 partials) against torch.nn.LSTM in f32 at T = 20 with a bound
+    on the MEAN error as well as the maximum (a max-only bound at 2e-2 would let a small systematic error of the
+    bf16 partial exchange through): outputs and every gradient within 3e-2 of the tensor's maximum, mean absolute error
+    within 2.5e-3 of it (bf16 rounding of operands and partials is zero-mean: the mean error sits an order below the maximum),
+    and the SIGNED mean error within 5e-4 (no bias)."""
+    T, I, H, L = 20, 80, 256, 2
+    torch.manual_seed(B + Ic)
+    lstm = torch.nn.LSTM(I + Ic, H, L)
+    names = [n + "_l%d" % l for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    params = [getattr(lstm, n).detach().cuda() for n in names]
+    x, xc = torch.randn(T, B, I), (torch.randn(B, Ic) if Ic else None)
+    g_out, g_hn = torch.randn(T, B, H), torch.randn(B, L * H)
+    a = _run(hb, x.cuda(), xc.cuda() if Ic else None, T, params, g_out.cuda(), g_hn.cuda(), cluster=True)
+    assert hb.LAST_LSTM_FORM["form"] == 1 and hb.lstm_sync_status() == 0
+    xin = torch.cat([x] + ([xc[None].expand(T, B, Ic)] if Ic else []), -1).requires_grad_(True)
+    out, (hn, _) = lstm(xin)
+    hn_cat = torch.cat([hn[l] for l in range(L)], -1)
+    ((out * g_out).sum() + (hn_cat * g_hn).sum()).backward()
+    pairs = [("hs_top", a[0].cpu(), out.detach()), ("hn", a[1].cpu(), hn_cat.detach())]
+    pairs += [(n, g.cpu(), getattr(lstm, n).grad) for n, g in zip(names, a[2])]
+    if Ic:
+        pairs.append(("d_xc", a[3].cpu(), xin.grad[:, :, I:].sum(0)))
+    for n, got, want in pairs:
+        scale = want.abs().max().item()
+        d = got - want
+        assert d.abs().max().item() <= 3e-2 * scale, (n, "max", d.abs().max().item(), scale)
+        assert d.abs().mean().item() <= 2.5e-3 * scale, (n, "mean", d.abs().mean().item(), scale)
+        assert abs(d.mean().item()) <= 5e-4 * scale, (n, "bias", d.mean().item(), scale)

@@ -30,12 +30,12 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     step()
     torch.cuda.synchronize()
 rows = []
-for ka in prof.key_averages(group_by_stack_n=6):
+for ka in prof.key_averages(group_by_stack_n=12):
     t = getattr(ka, "self_device_time_total", None)
     if t is None:
         t = getattr(ka, "self_cuda_time_total", 0.0)
-    if ka.key.startswith("aten::") and t > 0:
-        st = [f for f in (ka.stack or []) if "pytorch-scalablefhvae_amd" in f or "aten_trace" in f][:3]
+    if (ka.key.startswith("aten::") or "Memcpy" in ka.key or "memcpy" in ka.key) and t > 0:
+        st = [f for f in (ka.stack or []) if ("scalablefhvae" in f or "aten_trace" in f or "bench.py" in f)][:4] or list(ka.stack or [])[:6]
         rows.append((t, ka.key, ka.count, st))
 for t, name, n, st in sorted(rows, key=lambda r: -r[0])[:30]:
     print("%-30s x%d  %.1f us" % (name, n, t))

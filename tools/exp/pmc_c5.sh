@@ -1,5 +1,8 @@
+#!/bin/bash
+# c5 counter table (MfmaUtil, SQ wait/busy, instruction mix) of the K5 / cell / f32 weight-gradient kernels; run on the GPU box
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 ARGS="--config c5 --no-graph --no-roofline --no-cpu-baseline --no-alt --no-hbm --steps 3 --warmup 1"
 rm -rf /tmp/p1 /tmp/p2 /tmp/p3
 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d /tmp/p1 -- python3 $R/bench.py $ARGS > /dev/null 2>&1
