@@ -180,38 +180,41 @@ __global__ __launch_bounds__(kFwThreads) void lstm_fwd_wr_kernel(ClFwd p) {
     if (xvar) fw_dma_x<NPX>(img_x, x_rs, voff_x, 0u, nchx, wv * NPX, lane);
   }
 
-  // the saved-for-backward stores of step sp (c, the activated gates unit-major) and the f32 copies of h, out of the staging area:
-  // waves 0-3 (waves 4-7 poll B and request the h^1 image meanwhile), 16 bytes per thread and piece, 16 / 8 consecutive lanes per row
-  auto tail_stores = [&](int sp) {
-    if (wv >= 4) return;
+  // the saved-for-backward stores of layer l of step sp (c, the activated gates unit-major) and the f32 copies of h, out of the
+  // staging area: one half of the workgroup (waves 0-3 or 4-7), 16 bytes per thread and piece, 16 / 8 consecutive lanes per row.
+  // Round 4: the two layers go out at different points of the step and from different waves -- layer 0 (ready after P4) from
+  // waves 4-7 during P7, where they have nothing else to do and nothing latency-critical queued behind the stores (a wave's vector
+  // memory operations complete in order); layer 1 (ready after P8) from waves 0-3 in P2 of the next step as before.  All of it in
+  // P2 meant 56 KB per CU, 14 MB over the chip, in one burst at the HBM's rate with waves 0-3 blocked on the issue while the
+  // other four waited for them at the next barrier (P2 + P3 2.1 us of an 8.4-us step).
+  auto tail_stores = [&](int sp, int l, int wbase) {
+    if (wv < wbase || wv >= wbase + 4) return;
+    const int tq = tid - wbase * 64;
+    const int t = sp - l;
+    if (t < 0 || t >= T) return;
+    const int64_t lt = (int64_t)l * T + t;
+    const char* st = stage_all + l * kStageL;
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
-      const int t = sp - l;
-      if (t < 0 || t >= T) continue;
-      const int64_t lt = (int64_t)l * T + t;
-      const char* st = stage_all + l * kStageL;
+    for (int i = 0; i < ROWS * 16 / 256; ++i) {  // gates: 16 chunks per row
+      const int c = i * 256 + tq, rw = c >> 4, part = c & 15;
+      const uint4 v = *(const uint4*)(st + rw * kGS + part * 16);
+      if (r0 + rw < rend) *(uint4*)(p.gates + (lt * B + r0 + rw) * G + um * 4 + part * 8) = v;
+    }
+    const bool top = l == 1 && p.hs_top_f32, last = p.hn && t == T - 1;
 #pragma unroll
-      for (int i = 0; i < ROWS * 16 / 256; ++i) {  // gates: 16 chunks per row
-        const int c = i * 256 + tid, rw = c >> 4, part = c & 15;
-        const uint4 v = *(const uint4*)(st + rw * kGS + part * 16);
-        if (r0 + rw < rend) *(uint4*)(p.gates + (lt * B + r0 + rw) * G + um * 4 + part * 8) = v;
-      }
-      const bool top = l == 1 && p.hs_top_f32, last = p.hn && t == T - 1;
-#pragma unroll
-      for (int i = 0; i < ROWS * 8 / 256; ++i) {  // c (f32), f32 h: 8 chunks per row each
-        const int c = i * 256 + tid, rw = c >> 3, part = c & 7;
-        const uint4 v = *(const uint4*)(st + ROWS * kGS + rw * kCS + part * 16);
-        if (r0 + rw < rend) *(uint4*)(p.cs + (lt * B + r0 + rw) * H + um + part * 4) = v;
-        if (top || last) {
-          const uint4 hv = *(const uint4*)(st + ROWS * (kGS + kCS) + rw * kCS + part * 16);
-          if (r0 + rw < rend) {
-            if (top) *(uint4*)(p.hs_top_f32 + ((int64_t)t * B + r0 + rw) * H + um + part * 4) = hv;
-            if (last) {
-              *(uint4*)(p.hn + (int64_t)(r0 + rw) * (2 * H) + l * H + um + part * 4) = hv;
-              if (p.hn_lp) {  // the latent head's bf16 operand (fhvae_lstm_desc.hn_lp)
-                const float4 hf = __builtin_bit_cast(float4, hv);
-                *(uint2*)(p.hn_lp + (int64_t)(r0 + rw) * (2 * H) + l * H + um + part * 4) = pack4(f32x4{hf.x, hf.y, hf.z, hf.w});
-              }
+    for (int i = 0; i < ROWS * 8 / 256; ++i) {  // c (f32), f32 h: 8 chunks per row each
+      const int c = i * 256 + tq, rw = c >> 3, part = c & 7;
+      const uint4 v = *(const uint4*)(st + ROWS * kGS + rw * kCS + part * 16);
+      if (r0 + rw < rend) *(uint4*)(p.cs + (lt * B + r0 + rw) * H + um + part * 4) = v;
+      if (top || last) {
+        const uint4 hv = *(const uint4*)(st + ROWS * (kGS + kCS) + rw * kCS + part * 16);
+        if (r0 + rw < rend) {
+          if (top) *(uint4*)(p.hs_top_f32 + ((int64_t)t * B + r0 + rw) * H + um + part * 4) = hv;
+          if (last) {
+            *(uint4*)(p.hn + (int64_t)(r0 + rw) * (2 * H) + l * H + um + part * 4) = hv;
+            if (p.hn_lp) {  // the latent head's bf16 operand (fhvae_lstm_desc.hn_lp)
+              const float4 hf = __builtin_bit_cast(float4, hv);
+              *(uint2*)(p.hn_lp + (int64_t)(r0 + rw) * (2 * H) + l * H + um + part * 4) = pack4(f32x4{hf.x, hf.y, hf.z, hf.w});
             }
           }
         }
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(kFwThreads) void lstm_fwd_wr_kernel(ClFwd p) {
         fw_dma_h<NPH>(img_h1, hs_rs, voff_h, (unsigned)(T + s - 2) * slab_h, (wv - 4) * NPH);
       }
     }
-    if (s > 0) tail_stores(s - 1);
+    if (s > 0) tail_stores(s - 1, 1, 0);  // layer 1 of the previous step (layer 0 left in its P7)
     // ---- P3
     auto mm = [&](auto l_c, const char* img, const bf16x8 (&w)[8]) {  // acc[l] += image . w: the fragment of item i + 2 is requested
       constexpr int l = decltype(l_c)::value;                         // before the MFMA of item i
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(kFwThreads) void lstm_fwd_wr_kernel(ClFwd p) {
         if (xvar && s + 1 < T) fw_dma_x<NPX>(img_x, x_rs, voff_x, (unsigned)(s + 1) * slab_x, nchx, wv * NPX, lane);
       }
     }
+    if (act0) tail_stores(s, 0, 4);  // waves 4-7: layer 0 of this step (its staging area is rewritten in P4 of the next step, behind a barrier)
     CL_TLOG(s * 8 + 6);
     // ---- P8
     if (act1) {
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(kFwThreads) void lstm_fwd_wr_kernel(ClFwd p) {
     CL_TLOG(s * 8 + 7);
   }
   __syncthreads();
-  tail_stores(T);
+  tail_stores(T, 1, 0);
 }
 
 template __global__ void lstm_fwd_wr_kernel<2>(ClFwd);
