@@ -722,7 +722,8 @@ class _LstmSeq(torch.autograd.Function):
         cs = torch.empty(L, T, B, H, **f32)
         gates = torch.empty(L, T, B, 4 * H, device=dev, dtype=hs.dtype)
         hn = torch.empty(B, L * H, **f32)
-        hn_lp = torch.empty(B, L * H, device=dev, dtype=torch.bfloat16) if bf else None  # the latent head's bf16 operand
+        # the latent head's bf16 operand: only where the final states ARE the output (the encoders: top == 0)
+        hn_lp = torch.empty(B, L * H, device=dev, dtype=torch.bfloat16) if (bf and top == 0) else None
         if not bf:
             top = 2
         hs_top = torch.empty(T, B, H, **f32) if (bf and top != 0) else None

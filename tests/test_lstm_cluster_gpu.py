@@ -224,7 +224,7 @@ def test_forward_leaves_the_heads_bf16_operands(hb):
         params = [getattr(lstm, n).detach().cuda() for n in names]
         K = L * H
         w_mu, w_lv = torch.randn(Dh, K).cuda(), torch.randn(Dh, K).cuda()
-        hs, hn = hb.lstm_seq(torch.randn(T, B, I).cuda(), None, T, params, hb.BF16, head=(w_mu, w_lv))
+        hs, hn = hb.lstm_seq(torch.randn(T, B, I).cuda(), None, T, params, hb.BF16, top=0, head=(w_mu, w_lv))  # an encoder
         assert hb.lstm_sync_status() == 0
         assert torch.equal(hn._fh_lp, hn.to(torch.bfloat16))
         wl, wt = hn._fh_head
