@@ -140,3 +140,88 @@ def test_empty_shard_rank_takes_part():
     for r in range(world):
         assert all(np.isfinite(ret[r]["losses"])) and ret[r]["status"] == 0 and ret[r]["table"].shape == (2, D)
         assert torch.equal(ret[r]["table"], ret[0]["table"])
+
+
+# ---- the bf16 compute mode on two ranks: bf16 step cells (the persistent kernels need the whole GPU: FHVAE_NO_CLUSTER), the heads
+# on the projection kernel with the stacked weights from the nets' operand-cast launch, K5 on the split-operand bf16 MFMA kernels
+# over row shards merged across ranks, sign * CE riding in the kernels, deferred weight gradients + the early all-reduce hook
+H2, D2, BL2, S2B = 128, 32, 32, 2048
+
+
+def _build_bf16():
+    from fhvae import FHVAE
+
+    torch.manual_seed(13)
+    return FHVAE(T * F, [H2, H2], [H2, H2], D2, D2, [H2, H2], num_seqs=S2B, reference_compat=False, compute_dtype="bf16").cuda()
+
+
+def _data_bf16(world):
+    g = torch.Generator().manual_seed(9)
+    n = world * BL2
+    return (torch.randn(n, T, F, generator=g), torch.randint(0, S2B, (n,), generator=g), torch.randint(20, 200, (n,), generator=g),
+            torch.randn(n, D2, generator=g), torch.randn(n, D2, generator=g))
+
+
+def _worker_bf16(rank, world, port, ret):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "pytorch-scalablefhvae_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FHVAE_NO_CLUSTER="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hip_binding as hb
+    from dist_shard import DistributedFHVAE
+
+    x, idx, ns, e2, e1 = _data_bf16(world)
+    sl = slice(rank * BL2, (rank + 1) * BL2)
+    m = _build_bf16()
+    runner = DistributedFHVAE(m, lr=1e-3, betas=(0.95, 0.999))
+    assert runner.overlap and runner.sh.backend.lp
+    fwd = m.forward
+    m.forward = lambda *a, **k: fwd(*a, eps=(e2[sl].cuda(), e1[sl].cuda()), **k)
+    used0 = hb.PAIR_SIDE["used"]
+    losses = [runner.train_step(x[sl].cuda(), idx[sl].cuda(), ns[sl].cuda(), alpha=10.0)[0].item() for _ in range(3)]
+    ret[rank] = dict(losses=losses, shard=runner.shard.detach().cpu(), rows=(runner.sh.row0, runner.sh.row1),
+                     w=m.z1_pre_encoder.lstm.weight_hh_l1.detach().cpu(), wh=m.dec_gauss_layer.mulayer.weight.detach().cpu(),
+                     status=runner.check_status(), pair_used=hb.PAIR_SIDE["used"] - used0)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_bf16_mode_match_single_process_global_batch():
+    from hip_optim import FusedAdam
+    from train_model import loss_function
+
+    world = 2
+    x, idx, ns, e2, e1 = _data_bf16(world)
+    old = os.environ.get("FHVAE_NO_CLUSTER")
+    os.environ["FHVAE_NO_CLUSTER"] = "1"
+    try:
+        m = _build_bf16()
+        opt = FusedAdam(m.parameters(), lr=1e-3, betas=(0.95, 0.999))
+        ref_losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            out = m(x.cuda(), idx, S2B, ns, eps=(e2, e1))
+            loss = loss_function(out[0], out[1], 10.0)
+            loss.backward()
+            opt.step()
+            ref_losses.append(loss.item())
+        ret = mp.Manager().dict()
+        mp.spawn(_worker_bf16, args=(world, 29500 + os.getpid() % 150, ret), nprocs=world, join=True)
+    finally:
+        if old is None:
+            os.environ.pop("FHVAE_NO_CLUSTER", None)
+        else:
+            os.environ["FHVAE_NO_CLUSTER"] = old
+    assert ret[0]["rows"] == (0, 1024) and ret[1]["rows"] == (1024, 2048)
+    for k in range(3):  # same bf16 kernels on a split batch: operand rounding is per element, the f32 sums differ in order only
+        got = 0.5 * (ret[0]["losses"][k] + ret[1]["losses"][k])
+        assert abs(got - ref_losses[k]) <= 5e-4 * abs(ref_losses[k]), (k, got, ref_losses[k])
+    table = m.mu2_table.detach().cpu()
+    for r in range(world):
+        a, b = ret[r]["rows"]
+        assert ret[r]["status"] == 0 and ret[r]["pair_used"] == 3   # the per-frame head took the lower bound's ready-made operand every step
+        torch.testing.assert_close(ret[r]["shard"], table[a:b], rtol=1e-3, atol=3e-4)
+        torch.testing.assert_close(ret[r]["w"], m.z1_pre_encoder.lstm.weight_hh_l1.detach().cpu(), rtol=1e-3, atol=3e-4)
+        torch.testing.assert_close(ret[r]["wh"], m.dec_gauss_layer.mulayer.weight.detach().cpu(), rtol=1e-3, atol=3e-4)
+    assert torch.equal(ret[0]["w"], ret[1]["w"]) and torch.equal(ret[0]["wh"], ret[1]["wh"])   # replicas stay bit-identical
