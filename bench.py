@@ -461,6 +461,8 @@ def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no
     if use_graph and runner is not None and world > 1:
         # the multi-rank step, eagerly, FIRST: a valid measurement exists before the captured form is tried
         dt, loss, lb = timed(eager_step)
+        if hb.lstm_sync_status() != 0:
+            raise SystemExit("a persistent LSTM recurrence launch gave up (status %d): results invalid" % hb.lstm_sync_status())
         eager = {"value": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "elbo_nats_per_frame": (lb.mean() / T).item(),
                  "loss_finite": bool(torch.isfinite(loss).item()), "launch": "eager", "dtype": dtype, "batch": B}
         if on_eager is not None:
