@@ -497,7 +497,7 @@ int disc_mfma_bwd(const float* q, const float* table, const int64_t* idx, int64_
   a.rsum = rsum;
   a.gsc = gsc;
   a.gmul = gmul;
-  const int64_t gtiles = (dq && dtable && ws && !getenv("FHVAE_DISC_TWO_PASS")) ? onepass_group_tiles(ws_bytes, B, S, D) : 0;
+  const int64_t gtiles = (dq && dtable && ws) ? onepass_group_tiles(ws_bytes, B, S, D) : 0;
   if (gtiles > 0) {
     // one pass: stationary = queries, streamed = table rows; dq as in the two-pass form, dtable from the same weights.  Query
     // groups of gtiles tiles, one after the other on the same workspace (dtable accumulates over the groups)

@@ -329,7 +329,7 @@ int launch_gemm_group(const GemmParams* ps, int n, int dtype, hipStream_t st) {
   if (n <= 0) return FHVAE_OK;
   const bool bf = dtype == FHVAE_BF16;
   const int epc = bf ? 8 : 4;
-  bool ok = n > 1 && n <= kMaxGroup && !getenv("FHVAE_NO_GROUP");
+  bool ok = n > 1 && n <= kMaxGroup;
   int akc = -1, bkc = -1;
   int64_t tiles = 0;
   for (int i = 0; i < n && ok; ++i) {

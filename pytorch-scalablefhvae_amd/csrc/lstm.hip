@@ -505,7 +505,7 @@ static FwdJobs<T> fwd_jobs(const fhvae_lstm_desc* d, const Ops<T>& op, int64_t w
   FwdJobs<T> jobs = {};
   jobs.B = (int)B;
   jobs.H = (int)H;
-  jobs.glds = getenv("FHVAE_NO_GLDS") ? 0 : 1;
+  jobs.glds = 1;
   nj = 0;
   for (int l = 0; l < L; ++l) {
     const int64_t t = w - l;
@@ -722,7 +722,7 @@ static BwdJobs<T> bwd_jobs(const fhvae_lstm_bwd_desc* bd, const Ops<T>& op, int6
   BwdJobs<T> jobs = {};
   jobs.B = (int)B;
   jobs.H = (int)H;
-  jobs.glds = getenv("FHVAE_NO_GLDS") ? 0 : 1;
+  jobs.glds = 1;
   nj = 0;
   // f32: the weights are read untransposed as KM operands; bf16: the transposed copies [H,4H] are KC operands.
   for (int l = L - 1; l >= 0; --l) {

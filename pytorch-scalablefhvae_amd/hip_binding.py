@@ -1029,6 +1029,10 @@ def raw_disc_fwd(q, table, idx, row0=0, want_ce=True, lp=False, out3=None, ce_sc
     return rmax, rsum, tgt, ce
 
 
+#: default workspace size of the one-pass K5 backward: None = the library's recommendation; 0 = two passes (tests / tools)
+DISC_BWD_WS = {"bytes": None}
+
+
 def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True, need_dt=True, dt_sink=None, lp=False, ws_bytes=None):
     """ws_bytes: size of the one-pass form's workspace (default: the library's recommendation, capped at 1.5 GiB; a smaller
     workspace makes the kernels take the queries in groups; 0 = two passes)."""
@@ -1038,6 +1042,8 @@ def raw_disc_bwd(q, table, idx, rmax, rsum, g_scale, g_mul, row0=0, need_dq=True
     dq = torch.empty(B, D, device=q.device, dtype=torch.float32) if need_dq else None
     dt = dt_sink if dt_sink is not None else (torch.zeros(S, D, device=q.device, dtype=torch.float32) if need_dt else None)
     # workspace of the one-pass form (both gradients from one recomputation of the logits)
+    if ws_bytes is None:
+        ws_bytes = DISC_BWD_WS["bytes"]
     nws = int(lib.fhvae_disc_lse_bwd_ws_bytes(B, S, D)) if ws_bytes is None else int(ws_bytes)
     ws = torch.empty(nws, device=q.device, dtype=torch.uint8) if (need_dq and dt is not None and nws > 0) else None
     with _Timed("fhvae_disc_lse_bwd"):

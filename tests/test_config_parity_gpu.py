@@ -314,13 +314,13 @@ def test_disc_bf16_mode_vs_direct_f64(hb, B, S, scale, noise):
 
 @pytest.mark.parametrize("B,S,scale,noise", [(2048, 28000, 1.0, None), (300, 5000, 1.0, 0.05)])
 def test_disc_bf16_mode_two_pass_switch(hb, B, S, scale, noise):
-    """FHVAE_DISC_TWO_PASS=1: one recomputation of the logits per gradient (the form every call without a workspace takes)
-    instead of the one-pass backward; same tolerances."""
-    os.environ["FHVAE_DISC_TWO_PASS"] = "1"
+    """Without a workspace (hip_binding.DISC_BWD_WS = 0 bytes): one recomputation of the logits per gradient instead of the
+    one-pass backward; same tolerances.  (Round 4: the FHVAE_DISC_TWO_PASS switch is gone, the workspace size selects the form.)"""
+    hb.DISC_BWD_WS["bytes"] = 0
     try:
         _disc_bf16_case(hb, B, S, scale, noise)
     finally:
-        os.environ.pop("FHVAE_DISC_TWO_PASS", None)
+        hb.DISC_BWD_WS["bytes"] = None
 
 
 def _disc_bf16_case(hb, B, S, scale, noise):

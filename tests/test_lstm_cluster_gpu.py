@@ -160,8 +160,6 @@ SWITCHES = [("FHVAE_NO_CLUSTER", "1", (1024, 4, 80, 32, 256, 2), {}),      # per
             ("FHVAE_NO_FOLD", "1", (1024, 4, 80, 32, 256, 2), {}),         # layer-0 input projection as a GEMM
             ("FHVAE_NO_XC_FOLD", "1", (1024, 4, 0, 64, 256, 2), {}),       # time-constant projection as a GEMM
             ("FHVAE_NO_WGRAD", "1", (1024, 4, 80, 32, 256, 2), {}),        # weight gradients on the generic engine
-            ("FHVAE_NO_GLDS", "1", (256, 4, 80, 32, 256, 2), {"FHVAE_NO_CLUSTER": "1"}),   # step cells staged through registers
-            ("FHVAE_NO_GROUP", "1", (256, 4, 80, 32, 256, 2), {"FHVAE_NO_CLUSTER": "1"}),  # no grouped GEMM launches
             ("FHVAE_CLUSTER_TLOG", "1", (1024, 4, 80, 32, 256, 2), {}),    # phase-clock logging of the persistent kernels (tools/prof_*.py)
             ("FHVAE_BIG_CELLS", "1", (256, 4, 80, 32, 512, 2), {}),        # large-tile cells forced on
             ("FHVAE_BIG_CELLS", "0", (2048, 3, 80, 32, 512, 2), {})]       # ... and off where they are the default
