@@ -166,7 +166,7 @@ typedef struct fhvae_lstm_desc {
                     buffer (2*L*B*4H bf16): keep it alive and untouched between the forward and its backward */
   void* hn_lp;   /* BF16 mode, optional (may be NULL): (B, L*H) bf16 copy of hn -- the operand of a bf16 Gaussian head
                     (simple_fhvae.py:193-216) straight from the kernel that produced the final states, instead of a cast launch
-                    per head and step.  Always filled when set (the schedules without the fused store cast hn at the end). */
+                    per head and step.  Always filled when set (the persistent kernels store it with hn; the per-step schedules cast hn at the end). */
   /* BF16 mode, optional (head_w_mu == NULL: none): the Gaussian head that consumes this net's states (GaussianLayer,
      simple_fhvae.py:193-216; f32 master weights head_w_mu / head_w_lv [head_D, head_K]).  The forward's operand-cast launch then
      also writes the head's stacked bf16 operands -- head_wl [2 head_D, head_K] = [W_mu; W_lv] and head_wt [head_K, head_ldt] =

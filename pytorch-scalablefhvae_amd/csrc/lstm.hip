@@ -705,7 +705,7 @@ extern "C" int fhvae_lstm_seq_fwd(const fhvae_lstm_desc* d, void* stream) {
   e = lstm_fwd_impl<u16>(d, ops_bf16(d), st);
   if (e || !d->hn_lp) return e;
   if (!d->hn) return FHVAE_ERR_NULL;
-  if (cluster_eligible(d) && cluster_fwd_wr_ok(d)) return FHVAE_OK;  // lstm_fwd_wr.hip stored the bf16 copy beside hn
+  if (cluster_eligible(d)) return FHVAE_OK;  // the persistent forward kernels stored the bf16 copy beside hn
   const int64_t n = d->B * d->L * d->H;
   hipLaunchKernelGGL(cast_hn_kernel, dim3((unsigned)fh_cdiv(n, 256)), dim3(256), 0, st, d->hn, (u16*)d->hn_lp, n);
   return fh_launch_status();

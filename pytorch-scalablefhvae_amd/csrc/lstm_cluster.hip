@@ -187,7 +187,10 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_cluster_kernel(ClFwd p) {
         *(f32x4*)(p.cs + (lt * B + row) * H + uq) = creg[ll][tm];
         cl_store_gates(p.gates + (lt * B + row) * (4 * H), uq, gpk[ll][tm]);
         if (ll == L - 1 && p.hs_top_f32) *(f32x4*)(p.hs_top_f32 + ((int64_t)t * B + row) * H + uq) = hreg[ll][tm];
-        if (p.hn && t == T - 1) *(f32x4*)(p.hn + (int64_t)row * (L * H) + ll * H + uq) = hreg[ll][tm];
+        if (p.hn && t == T - 1) {
+          *(f32x4*)(p.hn + (int64_t)row * (L * H) + ll * H + uq) = hreg[ll][tm];
+          if (p.hn_lp) *(uint2*)(p.hn_lp + (int64_t)row * (L * H) + ll * H + uq) = pack4(hreg[ll][tm]);  // (fhvae_lstm_desc.hn_lp)
+        }
       }
     }
   };
@@ -1009,7 +1012,10 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_ksplit_kernel(ClFwd p) {
       *(f32x4*)(p.cs + (lt * B + row) * H + uq) = creg;
       cl_store_gates(p.gates + (lt * B + row) * (4 * H), uq, gpk);
       if (kp == L - 1 && p.hs_top_f32) *(f32x4*)(p.hs_top_f32 + ((int64_t)t * B + row) * H + uq) = hreg;
-      if (p.hn && t == T - 1) *(f32x4*)(p.hn + (int64_t)row * (L * H) + kp * H + uq) = hreg;
+      if (p.hn && t == T - 1) {
+        *(f32x4*)(p.hn + (int64_t)row * (L * H) + kp * H + uq) = hreg;
+        if (p.hn_lp) *(uint2*)(p.hn_lp + (int64_t)row * (L * H) + kp * H + uq) = pack4(hreg);  // (fhvae_lstm_desc.hn_lp)
+      }
     }
   }
 }
@@ -1339,7 +1345,7 @@ int cluster_fwd(const fhvae_lstm_desc* d, const ClusterWeights& w, hipStream_t s
     p.gates = (u16*)d->gates;
     p.hs_top_f32 = d->hs_top_f32;
     p.hn = d->hn;
-    p.hn_lp = wr ? (u16*)d->hn_lp : nullptr;
+    p.hn_lp = (u16*)d->hn_lp;  // every persistent forward stores the bf16 copy beside hn
     p.sync = (unsigned*)d->lp;
     p.xch = w.xch;
     p.tlog = getenv("FHVAE_CLUSTER_TLOG") ? (unsigned long long*)((char*)d->lp + FHVAE_LSTM_SYNC_BYTES * 3 / 4) : nullptr;

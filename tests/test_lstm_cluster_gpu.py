@@ -214,7 +214,8 @@ def test_forward_leaves_the_heads_bf16_operands(hb):
     import ctypes as C
 
     lib = hb.load_library()
-    for B, H, L, Dh in ((2048, 256, 2, 32), (256, 256, 2, 32), (192, 128, 1, 80)):  # wr forward / k-split cluster / generic
+    # register-stationary forward / k-split cluster (two and one layer) / rows-form cluster at H = 128 / per-step cells (cast at the end)
+    for B, H, L, Dh in ((2048, 256, 2, 32), (256, 256, 2, 32), (192, 128, 1, 80), (2048, 128, 2, 32), (192, 64, 1, 80)):
         torch.manual_seed(B + H)
         T, I = 5, 80
         lstm = torch.nn.LSTM(I, H, L)
