@@ -1193,6 +1193,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_ksplit_kernel(ClBwd p) {
   if (p.dgsum && kp == 0 && row < rend) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) *(f32x4*)(p.dgsum + (int64_t)row * G + g * H + uq) = dgs[g];
+    // one lane per row clears the row of d_xc for the split-K contraction that follows (lstm.hip: no zeroing launch)
+    if (p.d_xc_zero && uq == 0)
+      for (int c = 0; c < p.Ic; ++c) p.d_xc_zero[(int64_t)row * p.Ic + c] = 0.f;
   }
   if (epi && (p.db_ih[kp] || p.db_hh[kp])) {
 #pragma unroll
@@ -1486,8 +1489,8 @@ static int cluster_bwd_layers(const fhvae_lstm_bwd_desc* bd, const ClusterWeight
   return FHVAE_OK;
 }
 
-// the partial-dh backward clears d_xc itself (its layer-0 launch covers every row once)
-bool cluster_bwd_zeroes_dxc(const fhvae_lstm_desc* d) { return cluster_bwd_rs(d); }
+// the partial-dh backward and the contraction-split backward clear d_xc themselves (their layer-0 epilogue covers every row once)
+bool cluster_bwd_zeroes_dxc(const fhvae_lstm_desc* d) { return cluster_bwd_rs(d) || cluster_form(d) == 2; }
 
 // the layer-by-layer backward (rows form, two layers or more) hands the from-above gradient to the lower layer through
 // bd->ws_below (T,B,H) f32
@@ -1524,6 +1527,7 @@ int cluster_bwd(const fhvae_lstm_bwd_desc* bd, const ClusterWeights& w, hipStrea
     p.hn_ld = L * H;
     p.dg = (u16*)bd->dgates;
     p.dgsum = d->Ic > 0 ? bd->dgsum : nullptr;
+    if (bd->d_xc && d->Ic > 0) p.d_xc_zero = bd->d_xc, p.Ic = (int)d->Ic;  // (cluster_bwd_zeroes_dxc)
     for (int l = 0; l < L; ++l) p.db_ih[l] = bd->db_ih[l], p.db_hh[l] = bd->db_hh[l];
     p.sync = (unsigned*)d->lp;
     p.xch = w.xch;
