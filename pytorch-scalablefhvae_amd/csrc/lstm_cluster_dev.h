@@ -122,7 +122,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // (2 GB of records: for loads / stores whose offsets are always valid.  Do NOT mask a lane by an "out-of-range" offset against this
 //  descriptor: the range check is offset < num_records, so 0x7ffffff0 is IN range -- a masked store needs the tensor's real size
-//  as num_records and an offset >= it, e.g. 0xfffffff0; found the hard way in round 4)
+//  as num_records and an offset >= it, e.g. 0xfffffff0; found the hard way in round 4, DESIGN 9.
+//  Second trap, same place: a 128-bit buffer STORE with an SGPR soffset still reads its data registers for a cycle or two after
+//  issue, and hipcc's hazard recogniser only pads the form without an SGPR offset -- a VALU write of the first data register right
+//  behind the store (e.g. the next LDS address) reached memory instead of the data, now and then.  Put `s_nop 1` behind such a store.)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
