@@ -427,7 +427,7 @@ def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no
         opt.zero_grad()
         out = model(x, idx, S, ns)
         loss = loss_function(out[0], out[1], 10.0)
-        loss.backward()
+        hb.backward(loss)
         opt.step()
         return loss.detach(), out[0].detach()
 

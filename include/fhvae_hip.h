@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FHVAE_ABI_VERSION 10
+#define FHVAE_ABI_VERSION 11
 
 enum { FHVAE_F32 = 0, FHVAE_BF16 = 1 };
 
@@ -92,9 +92,10 @@ int fhvae_gauss_reparam_pair_fwd(const float* out, int64_t ldo, const float* eps
                                  int64_t M, int64_t D, void* stream);
 /* g_lp[m, 0..D) = bf16(d_mu + d_sample), [D..2D) = bf16(d_logvar + d_sample * eps * 0.5 * exp(0.5 logvar)), [2D..ldg) = 0:
  * the upstream gradient of both linear layers of a head as one bf16 operand (any of d_mu / d_logvar / d_sample may be NULL;
- * d_sample needs eps and logvar; logvar has row stride ld_lv).  db_mu / db_lv [D] (may be NULL): the bias gradients, += the
+ * d_sample needs eps and logvar; d_sample has row stride ld_s -- a column slice of the following net's input gradient is taken
+ * as it is --, logvar has row stride ld_lv).  db_mu / db_lv [D] (may be NULL): the bias gradients, += the
  * column sums of the two halves of g_lp (nn.Linear's bias backward) from the same launch where a workgroup covers whole rows. */
-int fhvae_gauss_reparam_bwd_pair(const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
+int fhvae_gauss_reparam_bwd_pair(const float* d_mu, const float* d_logvar, const float* d_sample, int64_t ld_s, const float* eps,
                                  const float* logvar, int64_t ld_lv, void* g_lp, int64_t ldg, float* db_mu, float* db_lv,
                                  int64_t M, int64_t D, void* stream);
 /* Backward of both linear layers of a head (nn.Linear backward at simple_fhvae.py:197-198,:210-211) from the bf16 operand
@@ -391,13 +392,18 @@ int fhvae_loss_bwd(const float* g_loss, float alpha, float* d_lower_bound, float
 
 /* ------------------------------------------------------------------------------------------
  * Adam (train_model.py:409-411: torch.optim.Adam(lr, betas=(beta_one, beta_two)), eps 1e-8, no
- * weight decay) over one flat f32 buffer; step_count is read from device memory (int32, already
- * incremented by this call) so a captured graph advances the bias correction.  p_lp (optional)
+ * weight decay) over one flat f32 buffer; step_count is read from device memory (int32; already
+ * incremented by the caller unless FHVAE_ADAM_ADVANCE) so a captured graph advances the bias correction.  p_lp (optional)
  * receives the updated parameters in bf16.  grad_scale multiplies g first (1/world for DP).
  * ------------------------------------------------------------------------------------------ */
-int fhvae_adam_step(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr,
-                    float beta1, float beta2, float eps, float grad_scale, int32_t* step_count,
+int fhvae_adam_step(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float grad_scale, int flags, int32_t* step_count,
                     void* stream);
+#define FHVAE_ADAM_ZERO_GRAD 1 /* g is cleared behind its use: the next backward accumulates into zeros, no memset launch */
+#define FHVAE_ADAM_ADVANCE 2   /* the launch counts the step itself: it uses step_count[0] + 1 and stores it; the words behind
+                                  it are its arrival counters (one per 128-byte line, zero between launches): step_count is
+                                  int32[FHVAE_ADAM_STEP_WORDS], 128-byte aligned -- no increment launch in front of it */
+#define FHVAE_ADAM_STEP_WORDS (65 * 32)
 
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg; no reference counterpart): while enabled, every step-cell launch

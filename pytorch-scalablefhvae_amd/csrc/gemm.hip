@@ -562,7 +562,7 @@ __global__ void reparam_pair_fwd_kernel(const float* __restrict__ out, int64_t l
 // and workgroup -- the column-sum launch that used to follow (colsum_kernel over g) is gone
 template <bool DB>
 __global__ __launch_bounds__(256) void reparam_bwd_pair_kernel(const float* __restrict__ d_mu, const float* __restrict__ d_lv,
-                                                               const float* __restrict__ d_s, const float* __restrict__ eps,
+                                                               const float* __restrict__ d_s, int64_t ld_s, const float* __restrict__ eps,
                                                                const float* __restrict__ lv, int64_t ld_lv, u16* __restrict__ g,
                                                                int64_t ldg, int64_t M, int D, float* __restrict__ db_mu,
                                                                float* __restrict__ db_lv) {
@@ -582,10 +582,10 @@ __global__ __launch_bounds__(256) void reparam_bwd_pair_kernel(const float* __re
     const int c = c0 + k;
     float v = 0.f;
     if (live && c < D) {
-      v = (d_mu ? d_mu[m * D + c] : 0.f) + (d_s ? d_s[m * D + c] : 0.f);
+      v = (d_mu ? d_mu[m * D + c] : 0.f) + (d_s ? d_s[m * ld_s + c] : 0.f);
     } else if (live && c < 2 * D) {
       const int64_t j = m * D + (c - D);
-      v = (d_lv ? d_lv[j] : 0.f) + ((d_s && eps) ? d_s[j] * eps[j] * 0.5f * expf(0.5f * lv[m * ld_lv + (c - D)]) : 0.f);
+      v = (d_lv ? d_lv[j] : 0.f) + ((d_s && eps) ? d_s[m * ld_s + (c - D)] * eps[j] * 0.5f * expf(0.5f * lv[m * ld_lv + (c - D)]) : 0.f);
     }
     o.h[k] = f2bf(v);
     if (DB) tile[threadIdx.x * 8 + k] = bf2f(o.h[k]);  // (the rounded value: what the weight-gradient contraction multiplies too)
@@ -813,23 +813,24 @@ extern "C" int fhvae_gauss_reparam_pair_fwd(const float* out, int64_t ldo, const
   return fh_launch_status();
 }
 
-extern "C" int fhvae_gauss_reparam_bwd_pair(const float* d_mu, const float* d_logvar, const float* d_sample, const float* eps,
+extern "C" int fhvae_gauss_reparam_bwd_pair(const float* d_mu, const float* d_logvar, const float* d_sample, int64_t ld_s, const float* eps,
                                             const float* logvar, int64_t ld_lv, void* g_lp, int64_t ldg, float* db_mu, float* db_lv,
                                             int64_t M, int64_t D, void* stream) {
   FH_CHECK_PTR(g_lp);
   FH_CHECK_POS(M);
   FH_CHECK_POS(D);
   if (d_sample && (!eps || !logvar)) return FHVAE_ERR_NULL;
+  if (d_sample && ld_s < D) return FHVAE_ERR_SHAPE;
   if (ldg < 2 * D || ldg % 8) return FHVAE_ERR_SHAPE;
   if (((uintptr_t)g_lp) & 15) return FHVAE_ERR_ALIGN;
   const dim3 grid((unsigned)fh_cdiv(M * (ldg / 8), 256));
   hipStream_t st = (hipStream_t)stream;
   if ((db_mu || db_lv) && 256 % (ldg / 8) == 0) {  // whole rows per workgroup: the bias gradients' column sums ride along
-    hipLaunchKernelGGL(reparam_bwd_pair_kernel<true>, grid, dim3(256), 0, st, d_mu, d_logvar, d_sample, eps, logvar, ld_lv, (u16*)g_lp,
+    hipLaunchKernelGGL(reparam_bwd_pair_kernel<true>, grid, dim3(256), 0, st, d_mu, d_logvar, d_sample, ld_s, eps, logvar, ld_lv, (u16*)g_lp,
                        ldg, M, (int)D, db_mu, db_lv);
     return fh_launch_status();
   }
-  hipLaunchKernelGGL(reparam_bwd_pair_kernel<false>, grid, dim3(256), 0, st, d_mu, d_logvar, d_sample, eps, logvar, ld_lv, (u16*)g_lp, ldg,
+  hipLaunchKernelGGL(reparam_bwd_pair_kernel<false>, grid, dim3(256), 0, st, d_mu, d_logvar, d_sample, ld_s, eps, logvar, ld_lv, (u16*)g_lp, ldg,
                      M, (int)D, nullptr, nullptr);
   int e = fh_launch_status();
   if (e || !(db_mu || db_lv)) return e;

@@ -644,10 +644,18 @@ __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v,
 }
 
 // 16 bytes per lane per stream (the arena is 64-element aligned); scalar tail
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// flags: FHVAE_ADAM_ZERO_GRAD -- g is cleared behind its use (the next backward accumulates into zeros: no memset launch);
+// FHVAE_ADAM_ADVANCE -- the step is step[0] + 1 and the last workgroup to finish stores it (every workgroup has read step[0]
+// before it counts itself in, so nobody reads the new value), instead of an increment launch in front of this one.  Counting in
+// two levels -- 64 group words, one per 128-byte line: step[32 (1 + (block & 63))], whose last arrivals count in step[1] --:
+// 3320 device-scope atomics on ONE word took 140 us, on 64 words of two adjacent lines still 85 (~30 ns each: atomics of one
+// LINE are serialised at the memory side); 52 per line on 64 lines + 64 on the top word are a chain of ~3 us
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, u16* __restrict__ plp, int64_t n, float lr, float b1, float b2,
-                            float eps, float gscale, const int32_t* __restrict__ step) {
-  const float t = (float)(*step);
+                            float eps, float gscale, int flags, int32_t* __restrict__ step) {
+  const int t_i = *(volatile int32_t*)step + ((flags & FHVAE_ADAM_ADVANCE) ? 1 : 0);
+  const float t = (float)t_i;
+  const bool zg = (flags & FHVAE_ADAM_ZERO_GRAD) != 0;
   const float lr_bc1 = lr / (1.f - powf(b1, t)), rs_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
   const int64_t n4 = n / 4;
   const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
@@ -664,6 +672,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
       ((float4*)p)[k] = pp;
       ((float4*)m)[k] = mm;
       ((float4*)v)[k] = vv;
+      if (zg) ((float4*)g)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (plp) {
         plp[4 * k] = f2bf(pp.x);
         plp[4 * k + 1] = f2bf(pp.y);
@@ -674,12 +683,28 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     i += n4 * 4;  // tail elements
     for (int64_t k = i; k < n; k += stride) {
       const float r = adam_one(p[k], g[k], m[k], v[k], lr_bc1, rs_bc2, b1, b2, eps, gscale);
+      if (zg) g[k] = 0.f;
       if (plp) plp[k] = f2bf(r);
     }
   } else {
     for (int64_t k = i; k < n; k += stride) {
       const float r = adam_one(p[k], g[k], m[k], v[k], lr_bc1, rs_bc2, b1, b2, eps, gscale);
+      if (zg) g[k] = 0.f;
       if (plp) plp[k] = f2bf(r);
+    }
+  }
+  if (flags & FHVAE_ADAM_ADVANCE) {
+    __syncthreads();  // (every thread of this workgroup has its t)
+    if (threadIdx.x == 0) {
+      const unsigned grp = blockIdx.x & 63u, ngrp = gridDim.x < 64u ? gridDim.x : 64u;
+      const unsigned members = (gridDim.x - grp + 63u) / 64u;  // workgroups with this group's low bits
+      if (atomicAdd((unsigned*)(step + 32 * (1 + grp)), 1u) == members - 1) {
+        step[32 * (1 + grp)] = 0;
+        if (atomicAdd((unsigned*)(step + 1), 1u) == ngrp - 1) {
+          step[1] = 0;
+          step[0] = t_i;
+        }
+      }
     }
   }
 }
@@ -996,8 +1021,9 @@ extern "C" int fhvae_disc_lse_bwd(const float* q, const float* table, const int6
   return FHVAE_OK;
 }
 
-extern "C" int fhvae_adam_step(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
-                               float beta2, float eps, float grad_scale, int32_t* step_count, void* stream) {
+extern "C" int fhvae_adam_step(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
+                               float beta2, float eps, float grad_scale, int flags, int32_t* step_count, void* stream) {
+  if (flags & ~(FHVAE_ADAM_ZERO_GRAD | FHVAE_ADAM_ADVANCE)) return FHVAE_ERR_SHAPE;
   FH_CHECK_PTR(p);
   FH_CHECK_PTR(g);
   FH_CHECK_PTR(m);
@@ -1008,7 +1034,7 @@ extern "C" int fhvae_adam_step(float* p, const float* g, float* m, float* v, voi
   if (blocks > 8192) blocks = 8192;  // grid-stride beyond that
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (u16*)p_lp, n, lr,
-                     beta1, beta2, eps, grad_scale, step_count);
+                     beta1, beta2, eps, grad_scale, flags, step_count);
   return fh_launch_status();
 }
 

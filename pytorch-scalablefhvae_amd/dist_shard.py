@@ -406,7 +406,7 @@ class DistributedFHVAE:
         loss = loss_function(out[0], out[1], alpha)
         hb.LSTM_BWD_REC_HOOK["fn"] = self._on_lstm_rec_done
         try:
-            loss.backward()
+            hb.backward(loss)
         finally:
             hb.LSTM_BWD_REC_HOOK["fn"] = None
         self._reduce_gradients()  # C1: the decoder + z1 buckets are already in flight under the z2 encoder's weight gradients

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfhvae_hip.so")
 
 F32, BF16 = 0, 1
 MAX_LAYERS = 4
-ABI_VERSION = 10  # FHVAE_ABI_VERSION of include/fhvae_hip.h
+ABI_VERSION = 11  # FHVAE_ABI_VERSION of include/fhvae_hip.h
 #: ``2*exp(pz2_logvar)`` evaluated exactly like simple_fhvae.py:88,:120 (numpy float32 arithmetic)
 PZ2_LOGVAR = np.log(0.5 ** 2).astype(np.float32)
 INV_TWO_VAR = float(np.float32(1.0) / (np.float32(2.0) * np.exp(PZ2_LOGVAR)))
@@ -93,7 +93,7 @@ SIGNATURES = {
     "fhvae_gauss_head_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_head_pair_weights": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_gauss_reparam_pair_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
-    "fhvae_gauss_reparam_bwd_pair": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "fhvae_gauss_reparam_bwd_pair": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "fhvae_elbo_colsum_rows": (_i64, [_i64]),
     "fhvae_gauss_head_bwd_pair": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_loss_fwd": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _vp, _vp]),
@@ -124,7 +124,7 @@ SIGNATURES = {
     "fhvae_disc_lse_bwd_ws_bytes": (_i64, [_i64, _i64, _i64]),
     "fhvae_disc_lse_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _i64, C.c_int, _vp]),
     "fhvae_disc_lse_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, _vp]),
-    "fhvae_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "fhvae_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, C.c_int, _vp, _vp]),
     "fhvae_segment_gather": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "fhvae_mu2_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "fhvae_mu2_finalize": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f32, _vp]),
@@ -547,10 +547,11 @@ class _GaussHeadLp(torch.autograd.Function):
             if g_lp is None:
                 d_mu = _f32c(d_mu) if d_mu is not None else None
                 d_lv = _f32c(d_lv) if d_lv is not None else None
-                d_s = _f32c(d_s) if d_s is not None else None
+                if d_s is not None and not (d_s.dtype == torch.float32 and d_s.dim() == 2 and d_s.stride(1) == 1 and d_s.stride(0) >= D):
+                    d_s = _f32c(d_s)  # (a column slice of the next net's input gradient -- cat's backward -- goes in as it is)
                 g_lp = torch.empty(M, ldg, device=dev, dtype=torch.bfloat16)
                 # (the two bias gradients = column sums of g_lp come out of the same launch)
-                _check(lib.fhvae_gauss_reparam_bwd_pair(_p(d_mu), _p(d_lv), _p(d_s), _p(eps), _p(lv), lv.stride(0), _p(g_lp), ldg,
+                _check(lib.fhvae_gauss_reparam_bwd_pair(_p(d_mu), _p(d_lv), _p(d_s), d_s.stride(0) if d_s is not None else D, _p(eps), _p(lv), lv.stride(0), _p(g_lp), ldg,
                                                         _p(outs[1]), _p(outs[3]), M, D, _stream()), "fhvae_gauss_reparam_bwd_pair")
                 db_done = True
             # every parameter has a gradient sink: the two weight-gradient contractions join the nets' grouped launch
@@ -1177,15 +1178,35 @@ def proj_bf16(a, w, bias=None, out=None):
     return out
 
 
-def adam_step_(p, g, m, v, step_dev, lr, beta1, beta2, eps, grad_scale=1.0, p_lp=None):
-    """In-place fused Adam on flat f32 views (train_model.py:409-411)."""
+ADAM_ZERO_GRAD, ADAM_ADVANCE, ADAM_STEP_WORDS = 1, 2, 65 * 32  # FHVAE_ADAM_* of include/fhvae_hip.h
+_ONES = {}
+
+
+def backward(loss: torch.Tensor):
+    """loss.backward() with a cached gradient seed: autograd's implicit ones_like is one fill launch per step."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _ONES.get(key)
+    if one is None:
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():  # (no persistent allocation inside a capture: the plain form this once)
+            loss.backward()
+            return
+        one = _ONES[key] = torch.ones_like(loss)
+    loss.backward(gradient=one)
+
+
+def adam_step_(p, g, m, v, step_dev, lr, beta1, beta2, eps, grad_scale=1.0, p_lp=None, flags=0):
+    """In-place fused Adam on flat f32 views (train_model.py:409-411).  step_dev: the int32 step count on the device, already
+    incremented -- or, with ADAM_ADVANCE, int32[ADAM_STEP_WORDS] ([0] the count, the rest the kernel's scratch words): the launch
+    counts the step itself.  ADAM_ZERO_GRAD clears g behind its use."""
     lib = load_library()
     _need_gpu(p, g, m, v, step_dev)
+    if (flags & ADAM_ADVANCE) and step_dev.numel() < ADAM_STEP_WORDS:
+        raise RuntimeError("ADAM_ADVANCE needs an int32[%d] step buffer (step count + scratch words)" % ADAM_STEP_WORDS)
     n = p.numel()
     if n == 0:  # an empty table shard (more ranks than rows)
         return
     with _Timed("fhvae_adam_step"):
-        _check(lib.fhvae_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, lr, beta1, beta2, eps, grad_scale, _p(step_dev),
+        _check(lib.fhvae_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, lr, beta1, beta2, eps, grad_scale, int(flags), _p(step_dev),
                                    _stream()), "fhvae_adam_step")
 
 

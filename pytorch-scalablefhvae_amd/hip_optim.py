@@ -4,7 +4,10 @@
 Parameters are packed into ONE flat f32 arena (parameters become views of it) so that the optimizer
 is a single elementwise launch per step and data-parallel gradient reduction is one (bucketed)
 collective over the flat gradient arena.  The step counter lives on the device so a captured
-hipGraph advances the bias correction on replay.
+hipGraph advances the bias correction on replay; the Adam launch counts the step itself and clears the
+gradient arena behind its use (FHVAE_ADAM_ADVANCE | FHVAE_ADAM_ZERO_GRAD), so a training step has no
+increment launch and no memset: `zero_grad()` right after `step()` finds the arena already zero.
+NOTE the one visible difference from torch.optim.Adam: after `step()` every `p.grad` reads zero.
 """
 from __future__ import annotations
 
@@ -47,7 +50,9 @@ class FusedAdam(torch.optim.Optimizer):
                 p._fh_grad = gv      # ... and the HIP backward kernels write there directly (hip_binding._sink)
         self.m = torch.zeros_like(self.p_arena.flat)
         self.v = torch.zeros_like(self.p_arena.flat)
-        self.step_dev = torch.zeros((), device=params[0].device, dtype=torch.int32)
+        self._step_buf = torch.zeros(hb.ADAM_STEP_WORDS, device=params[0].device, dtype=torch.int32)  # [0] the step count, then the kernel's scratch words
+        self.step_dev = self._step_buf[0]  # (0-dim view: .item() / .fill_() / .copy_() as before)
+        self._zeroed_by_step = False  # the last thing that touched the gradient arena was step(): it is all zeros
 
     # -- checkpoint contract (utils.py:87,131; train_model.py:415): torch.optim.Adam's state-dict layout, so the moments and the
     # step count survive a save / resume and a state saved by torch.optim.Adam over the same parameters loads here -----------
@@ -95,7 +100,10 @@ class FusedAdam(torch.optim.Optimizer):
         # keep the arena views attached (set_to_none would detach them); one memset for everything
         hb.flush_param_grads()  # (a backward that was never followed by step(): its queued kernels must not land after the memset)
         hb.join_side_stream()
-        self.g_arena.flat.zero_()
+        if self._zeroed_by_step:
+            self._zeroed_by_step = False  # (a backward follows: the arena will not be zero the next time)
+        else:
+            self.g_arena.flat.zero_()
         for p, gv in zip(self._params, self.g_arena.views):
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
                 p.grad = gv
@@ -114,6 +122,6 @@ class FusedAdam(torch.optim.Optimizer):
                 gv.copy_(p.grad)  # a gradient produced outside the arena (first backward after set_to_none)
                 p.grad = gv
         g = self.param_groups[0]
-        self.step_dev += 1
-        hb.adam_step_(self.p_arena.flat, self.g_arena.flat, self.m, self.v, self.step_dev, g["lr"], g["betas"][0],
-                      g["betas"][1], g["eps"], self.grad_scale)
+        hb.adam_step_(self.p_arena.flat, self.g_arena.flat, self.m, self.v, self._step_buf, g["lr"], g["betas"][0],
+                      g["betas"][1], g["eps"], self.grad_scale, flags=hb.ADAM_ZERO_GRAD | hb.ADAM_ADVANCE)
+        self._zeroed_by_step = True

@@ -248,7 +248,7 @@ def main(argv=None) -> int:
         optimizer.zero_grad()
         lower_bound, discrim_loss, log_px_z, neg_kld_z1, neg_kld_z2, log_pmu2 = model(features, idxs, S, nsegs)
         loss = loss_function(lower_bound, discrim_loss, args.alpha_dis)
-        loss.backward()
+        hb.backward(loss)  # (loss.backward() with a cached seed)
         optimizer.step()
         return loss.detach(), lower_bound.detach()
 

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), "libfhvae_hip.so lacks %s" % n
         assert n in hb.SIGNATURES, "hip_binding does not bind %s" % n
     assert set(hb.SIGNATURES) == set(names)
-    assert lib.fhvae_abi_version() == 10
+    assert lib.fhvae_abi_version() == 11
     assert lib.fhvae_strerror(-1) == b"required pointer is NULL"
 
 
@@ -71,7 +71,10 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     assert lib.fhvae_wgrad_f32(p, 6, p, 8, p, 8, 4, 8, 16, None) == -4                   # lda = 6 is not a multiple of 4
     assert lib.fhvae_head_pair_weights(p, p, p, p, 8, 8, 16, None) == -2                 # ldt = 8 < 2D = 16
     assert lib.fhvae_gauss_head_bwd_pair(None, 64, None, 64, None, 64, None, 0, None, 64, None, None, None, None, 8, 64, 8, None) == -1
-    assert lib.fhvae_gauss_reparam_bwd_pair(None, None, p, None, None, 8, p, 16, None, None, 4, 8, None) == -1   # d_sample without eps / logvar
+    assert lib.fhvae_gauss_reparam_bwd_pair(None, None, p, 8, None, None, 8, p, 16, None, None, 4, 8, None) == -1   # d_sample without eps / logvar
+    assert lib.fhvae_gauss_reparam_bwd_pair(None, None, p, 4, p, p, 8, p, 16, None, None, 4, 8, None) == -2      # ABI 11: ld_s = 4 < D = 8
+    assert lib.fhvae_adam_step(p, p, p, p, None, 16, 1e-3, 0.9, 0.999, 1e-8, 1.0, 4, p, None) == -2              # ABI 11: unknown flag bit
+    assert lib.fhvae_adam_step(p, p, p, p, None, 16, 1e-3, 0.9, 0.999, 1e-8, 1.0, 3, None, None) == -1           # no step buffer
     w = hb.WgradDesc(None, 8, 0, None, 8, None, 8, 8, 8, 64)
     assert lib.fhvae_wgrad_desc_ok(ctypes.byref(w)) == 0
     assert lib.fhvae_disc_lse_bwd_ws_bytes(2048, 28000, 32) > 0 and lib.fhvae_disc_lse_bwd_ws_bytes(8, 8, 32) == 0

@@ -477,6 +477,30 @@ def test_adam_matches_torch(hb):
     close(pd, ref, rtol=1e-5, what="adam p")
 
 
+@pytest.mark.parametrize("n", [1000, 103427, 3 * 8192 * 1024 + 5])
+def test_adam_counts_its_step_and_clears_the_gradient(hb, n):
+    """ABI 11: FHVAE_ADAM_ADVANCE (the launch uses step[0] + 1 and stores it; the last workgroup, so nobody reads the new value)
+    and FHVAE_ADAM_ZERO_GRAD (g cleared behind its use) give the same parameters as the increment-then-launch form -- also when
+    the grid is at its cap and grid-strides (the large case)."""
+    torch.manual_seed(n % 97)
+    p0 = torch.randn(n, device="cuda")
+    pa, pb = p0.clone(), p0.clone()
+    ma, va, mb, vb = (torch.zeros(n, device="cuda") for _ in range(4))
+    step_a = torch.zeros((), dtype=torch.int32, device="cuda")
+    step_b = torch.zeros(hb.ADAM_STEP_WORDS, dtype=torch.int32, device="cuda")
+    for k in range(3):
+        g = torch.randn(n, device="cuda")
+        ga, gb = g.clone(), g.clone()
+        step_a += 1
+        hb.adam_step_(pa, ga, ma, va, step_a, 1e-3, 0.95, 0.999, 1e-8)
+        hb.adam_step_(pb, gb, mb, vb, step_b, 1e-3, 0.95, 0.999, 1e-8, flags=hb.ADAM_ZERO_GRAD | hb.ADAM_ADVANCE)
+        assert torch.equal(ga, g) and float(gb.abs().max()) == 0.0
+        assert step_b.tolist() == [k + 1] + [0] * (hb.ADAM_STEP_WORDS - 1)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    with pytest.raises(RuntimeError):
+        hb.adam_step_(pb, gb, mb, vb, step_a, 1e-3, 0.95, 0.999, 1e-8, flags=hb.ADAM_ADVANCE)
+
+
 def test_fused_adam_arena_matches_torch_adam(hb):
     from hip_optim import FusedAdam
 
@@ -498,6 +522,15 @@ def test_fused_adam_arena_matches_torch_adam(hb):
     for a, b in zip(mine, ref):
         close(a, b, rtol=1e-5, what="fused adam")
     assert all(p.data_ptr() == v.data_ptr() for p, v in zip(mine, o_mine.p_arena.views))
+    # the Adam launch left the gradient arena zero and counted its step; zero_grad() after step() is then free, and a
+    # zero_grad() that follows a backward without a step still clears
+    assert int(o_mine.step_dev.item()) == 4 and float(o_mine.g_arena.flat.abs().max()) == 0.0 and o_mine._zeroed_by_step
+    o_mine.zero_grad()
+    assert not o_mine._zeroed_by_step
+    sum((p * 2.0).sum() for p in mine).backward()
+    assert float(o_mine.g_arena.flat.abs().max()) == 2.0
+    o_mine.zero_grad()
+    assert float(o_mine.g_arena.flat.abs().max()) == 0.0
 
 
 def test_fused_loss_matches_expression(hb):
@@ -560,13 +593,16 @@ def test_reparam_bwd_pair_bias_sums_ride_along(hb, M, D):
     launch where a workgroup covers whole rows (ldg/8 divides 256), and through the column-sum kernel otherwise."""
     lib = hb.load_library()
     g = torch.Generator().manual_seed(M + D)
-    d_mu, d_lv, d_s, eps = (torch.randn(M, D, generator=g).cuda() for _ in range(4))
+    d_mu, d_lv, eps = (torch.randn(M, D, generator=g).cuda() for _ in range(3))
+    # ABI 11: d_sample with a row stride -- a column slice of the next net's input gradient (cat's backward) as it is
+    d_s = torch.randn(M, 2 * D + 8, generator=g).cuda()[:, D:2 * D]
+    assert not d_s.is_contiguous()
     lv = (torch.randn(M, D, generator=g) * 0.3).cuda()
     ldg = (2 * D + 63) // 64 * 64
     g_lp = torch.empty(M, ldg, device="cuda", dtype=torch.bfloat16)
     db_mu, db_lv = torch.full((D,), 0.5, device="cuda"), torch.full((D,), -0.25, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.fhvae_gauss_reparam_bwd_pair(d_mu.data_ptr(), d_lv.data_ptr(), d_s.data_ptr(), eps.data_ptr(), lv.data_ptr(), D,
+    assert lib.fhvae_gauss_reparam_bwd_pair(d_mu.data_ptr(), d_lv.data_ptr(), d_s.data_ptr(), d_s.stride(0), eps.data_ptr(), lv.data_ptr(), D,
                                             g_lp.data_ptr(), ldg, db_mu.data_ptr(), db_lv.data_ptr(), M, D, st) == 0
     want_mu = d_mu + d_s
     want_lv = d_lv + d_s * eps * 0.5 * torch.exp(0.5 * lv)
