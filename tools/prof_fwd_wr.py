@@ -1,6 +1,7 @@
 """Phase clocks of the register-stationary forward recurrence (csrc/lstm_fwd_wr.hip), cluster 0 / member 0: FHVAE_CLUSTER_TLOG=1
-makes the kernel log wall_clock64() (100 MHz) per step at: 0 step begins, 1 h0 image landed, 2 layer 0's pre-activations done,
-3 layer 0's gate math + layer 1's MFMAs done, 4 A published, 5 layer 1's gate math done, 6 B published, 7 tail stores issued."""
+makes the kernel log wall_clock64() (100 MHz) per step at: 0 step begins, 1 images landed (P1), 2 layer 0's products done and the
+h1 image requested (P2 + P3), 3 layer 0's gate math done, 4 h0 out + A published, 5 layer 1's products of h0 done + barrier (P5, P6),
+6 layer 0's saved-for-backward stores issued (P7), 7 layer 1's recurrent products, the h0 request, gate math, h1 out, B published."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch-scalablefhvae_amd"))
 os.environ["FHVAE_CLUSTER_TLOG"] = "1"
