@@ -1,4 +1,6 @@
-"""Same-box A/B of a forward-kernel switch: alternate the two settings, 200 calls each, three rounds."""
+"""Same-box A/B of a forward-kernel switch (an environment variable the library reads per launch): alternate the two settings,
+200 calls each, three rounds.  Record of DESIGN 9 item 5: the switches it was used with (FHVAE_FWD_PEEK_OFF, FHVAE_FWD_LATE_A,
+FHVAE_FWD_TAIL8) existed only while the placements were compared; the library reads none of them now."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "pytorch-scalablefhvae_amd"))
 import torch
