@@ -29,6 +29,23 @@ __global__ void to_time_major_kernel(const float* __restrict__ x, T* __restrict_
   if (of) of[i] = v;
 }
 
+// the same with four features per thread (F % 4 == 0, 16-byte aligned buffers): 16-byte loads and f32 stores, 8-byte bf16 stores
+template <typename T>
+__global__ void to_time_major4_kernel(const float* __restrict__ x, T* __restrict__ o, float* __restrict__ of, int B, int T_, int F4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index into (T,B,F/4)
+  if (i >= (int64_t)B * T_ * F4) return;
+  const int f = (int)(i % F4);
+  const int64_t tb = i / F4;
+  const int b = (int)(tb % B), t = (int)(tb / B);
+  const float4 v = ((const float4*)x)[((int64_t)b * T_ + t) * F4 + f];
+  if constexpr (sizeof(T) == 4) {
+    ((float4*)o)[i] = v;
+  } else {
+    ((uint2*)o)[i] = uint2{(uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16), (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16)};
+  }
+  if (of) ((float4*)of)[i] = v;
+}
+
 __global__ void cast_bf16_kernel(const float* __restrict__ s, u16* __restrict__ d, u16* __restrict__ dt, int64_t R,
                                  int64_t C) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -735,6 +752,17 @@ extern "C" int fhvae_to_time_major(const float* x_btf, void* x_tbf, float* x_tbf
   FH_CHECK_POS(T);
   FH_CHECK_POS(F);
   const int64_t n = B * T * F;
+  if (dtype != FHVAE_F32 && dtype != FHVAE_BF16) return FHVAE_ERR_DTYPE;
+  if (F % 4 == 0 && B <= INT32_MAX && T <= INT32_MAX && ((((uintptr_t)x_btf) | ((uintptr_t)x_tbf) | ((uintptr_t)x_tbf_f32)) & 15) == 0) {
+    dim3 grid4((unsigned)fh_cdiv(n / 4, 256));
+    if (dtype == FHVAE_F32)
+      hipLaunchKernelGGL((to_time_major4_kernel<float>), grid4, dim3(256), 0, (hipStream_t)stream, x_btf, (float*)x_tbf, x_tbf_f32, (int)B,
+                         (int)T, (int)(F / 4));
+    else
+      hipLaunchKernelGGL((to_time_major4_kernel<u16>), grid4, dim3(256), 0, (hipStream_t)stream, x_btf, (u16*)x_tbf, x_tbf_f32, (int)B, (int)T,
+                         (int)(F / 4));
+    return fh_launch_status();
+  }
   dim3 grid((unsigned)fh_cdiv(n, 256));
   if (dtype == FHVAE_F32)
     hipLaunchKernelGGL((to_time_major_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x_btf, (float*)x_tbf,

@@ -344,9 +344,14 @@ def test_backward_refuses_a_forward_of_another_schedule(hb):
         hb.flush_param_grads()
 
 
-def test_to_time_major(hb):
-    x = torch.randn(6, 5, 12)
-    close(hb.to_time_major(dev(x)), x.transpose(0, 1).contiguous(), rtol=0)
+@pytest.mark.parametrize("B,T,F", [(6, 5, 12), (7, 3, 10), (300, 20, 80)])
+def test_to_time_major(hb, B, T, F):
+    """both forms of the copy: four features per thread (F % 4 == 0) and the scalar one; with the bf16 copy riding along"""
+    x = torch.randn(B, T, F)
+    want = x.transpose(0, 1).contiguous()
+    assert torch.equal(hb.to_time_major(dev(x)).cpu(), want)
+    both = hb.to_time_major(dev(x), with_bf16=True)
+    assert torch.equal(both.cpu(), want) and torch.equal(both._fh_lp.cpu(), want.bfloat16())
 
 
 @pytest.mark.parametrize("detach", [True, False])
