@@ -945,7 +945,10 @@ static int lstm_dxc(const fhvae_lstm_bwd_desc* bd, hipStream_t st, bool zeroed =
     const int64_t n = d->B * d->Ic;
     if (!zeroed) hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)fh_cdiv(n, 1024)), dim3(256), 0, st, bd->d_xc, n);
     p.mode = 2;
-    p.splitk = 4;
+    // about one workgroup per CU, slices of at least 128 (4 at B = 2048 left half the chip idle: 13.4 us per launch)
+    int64_t sk = 256 / tiles;
+    while (sk > 1 && G / sk < 128) sk >>= 1;
+    p.splitk = (int)(sk < 4 ? 4 : sk > 16 ? 16 : sk);
   } else {
     p.splitk = 1;
   }
