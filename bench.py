@@ -458,13 +458,30 @@ def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no
         return dt, loss, lb
 
     eager = None
-    if use_graph and runner is not None and world > 1:
-        # the multi-rank step, eagerly, FIRST: a valid measurement exists before the captured form is tried
+    eager_note = "eager"
+    if runner is not None and world > 1:
+        # the multi-rank step, eagerly, FIRST: a valid measurement exists before the captured form is tried (and with
+        # --no-dist-graph: the place where the ranks agree on the recurrences' status)
         dt, loss, lb = timed(eager_step)
-        if hb.lstm_sync_status() != 0:
-            raise SystemExit("a persistent LSTM recurrence launch gave up (status %d): results invalid" % hb.lstm_sync_status())
+        # A persistent recurrence needs all 256 CUs of its GPU at once; beside a collective kernel that never ran on hardware with
+        # this path before, a launch may give up (sticky status).  Every rank must take the same branch: agree on the status, then
+        # fall back to the per-step cells (FHVAE_NO_CLUSTER, read by the library per call) and measure again -- a slower valid
+        # number instead of none.
+        st_all = torch.tensor([hb.lstm_sync_status()], device=device, dtype=torch.int32)
+        dist.all_reduce(st_all, op=dist.ReduceOp.MAX)
+        if int(st_all.item()) != 0:
+            print("bench: a persistent LSTM recurrence launch gave up on some rank (status %d): measuring with the per-step cells"
+                  % int(st_all.item()), file=sys.stderr)
+            os.environ["FHVAE_NO_CLUSTER"] = "1"
+            hb.reset_device_words(device)
+            hb.LSTM_WORKSPACES.clear()
+            dt, loss, lb = timed(eager_step)
+            if hb.lstm_sync_status() != 0:
+                raise SystemExit("a persistent LSTM recurrence launch gave up (status %d): results invalid" % hb.lstm_sync_status())
+            eager_note = "eager, per-step cells (the persistent recurrences gave up beside the collectives: status %d)" % int(st_all.item())
+            use_graph = False  # (the captured form is not tried on top of a fallback)
         eager = {"value": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "elbo_nats_per_frame": (lb.mean() / T).item(),
-                 "loss_finite": bool(torch.isfinite(loss).item()), "launch": "eager", "dtype": dtype, "batch": B}
+                 "loss_finite": bool(torch.isfinite(loss).item()), "launch": eager_note, "dtype": dtype, "batch": B}
         if on_eager is not None:
             on_eager(eager)
     if use_graph:
@@ -497,7 +514,7 @@ def run_gpu(cfg_name, B, dtype, steps, warmup, device, rank, world, use_dist, no
     if hb.lstm_sync_status() != 0:
         raise SystemExit("a persistent LSTM recurrence launch gave up (status %d): results invalid" % hb.lstm_sync_status())
     res = {"value": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "elbo_nats_per_frame": elbo, "loss_finite": ok,
-           "launch": "hipGraph replay of the whole step" if use_graph else "eager", "dtype": dtype, "batch": B}
+           "launch": "hipGraph replay of the whole step" if use_graph else eager_note, "dtype": dtype, "batch": B}
     if eager is not None:
         res["eager"] = {"value": eager["value"], "ms_per_step": eager["ms_per_step"]}
     if os.environ.get("FHVAE_BENCH_RETRY"):
