@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 import hip_binding as hb
 SW = sys.argv[1] if len(sys.argv) > 1 else "FHVAE_FWD_PEEK_OFF"
+VAL = sys.argv[2] if len(sys.argv) > 2 else "1"
 B, T, H, L = 2048, 20, 256, 2
 for I, Ic in ((80, 0), (80, 32), (0, 64)):
     torch.manual_seed(0)
@@ -18,7 +19,7 @@ for I, Ic in ((80, 0), (80, 32), (0, 64)):
     for rnd in range(3):
         for off in (1, 0):
             if off:
-                os.environ[SW] = "1"
+                os.environ[SW] = VAL
             else:
                 os.environ.pop(SW, None)
             for _ in range(10):
