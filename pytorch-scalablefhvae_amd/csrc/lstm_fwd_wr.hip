@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "lstm_cluster_dev.h"
+
 #include "trace.h"
 
 namespace fh {
@@ -90,7 +91,7 @@ __device__ __forceinline__ void fw_dma_xc(char* img, const u16* xc, int Ic, cons
   }
 }
 
-template <int RT>
+template <int RT, int PDT = 4>
 __global__ __launch_bounds__(kFwThreads) void lstm_fwd_wr_kernel(ClFwd p) {
   constexpr int H = kFwH, G = kFwG;
   constexpr int ROWS = RT * 16;
@@ -286,18 +287,30 @@ __global__ __launch_bounds__(kFwThreads) void lstm_fwd_wr_kernel(ClFwd p) {
     // ---- P3
     auto mm = [&](auto l_c, const char* img, const bf16x8 (&w)[8], bool peek_a = false) {  // acc[l] += image . w: the fragment of item
       constexpr int l = decltype(l_c)::value;                                              // i + 2 is requested before the MFMA of item i
-      bf16x8 fb[3];
+      // Fragments in flight ahead of the MFMA that needs them, and the order PINNED (sched_barrier around every read and every
+      // MFMA).  Written as a plain software pipeline of depth 2, hipcc -- at 237 of the 256 registers two waves per SIMD leave --
+      // read every fragment into ONE register set and waited for it in front of its MFMA: a full LDS latency (~100 clk) per
+      // 16-clk MFMA, 2 us for layer 0's 48 products where the LDS array needs 0.6.  Found only in the ISA: with the
+      // saved-for-backward stores compiled out P2 + P3 kept its 2.0 us.  Same-box A/B (tools/exp/ab_fwd.py), depth 3 / 4 / 5 / the
+      // unpinned form: 162.0 / 161.2 / 164.5 / 185.4 us per forward call.
+      constexpr int PD = PDT;
+      bf16x8 fb[PD + 1];
       auto frag = [&](int i) {
         const int ks = i / RT, rt = i % RT;
-        fb[i % 3] = __builtin_bit_cast(bf16x8, *(const uint4*)(img + hbase[ks & 3] + (ks >> 2) * 256 + rt * 8192));
+        fb[i % (PD + 1)] = __builtin_bit_cast(bf16x8, *(const uint4*)(img + hbase[ks & 3] + (ks >> 2) * 256 + rt * 8192));
       };
-      frag(0);
-      frag(1);
+#pragma unroll
+      for (int i = 0; i < PD; ++i) frag(i);
+      if (PD > 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int ks = i / RT, rt = i % RT;
-        if (i + 2 < NI) frag(i + 2);
-        acc[l][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks], fb[i % 3], acc[l][rt], 0, 0, 0);
+        if (i + PD < NI) frag(i + PD);
+        // pin the order (one fragment read, one MFMA): left to itself hipcc reads every fragment into ONE register set and waits
+        // for it in front of its MFMA -- a full LDS latency per MFMA
+        if (PD > 2) __builtin_amdgcn_sched_barrier(0);
+        acc[l][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks], fb[i % (PD + 1)], acc[l][rt], 0, 0, 0);
+        if (PD > 2) __builtin_amdgcn_sched_barrier(0);
         if (i == NI - 1 && peek_a) peekA = flags_peek(flags);  // (A: published a P5 ago; looked at behind P8's products)
       }
     };
@@ -308,8 +321,10 @@ __global__ __launch_bounds__(kFwThreads) void lstm_fwd_wr_kernel(ClFwd p) {
         bf16x8 b[RT];  // (all reads of the k-step in flight before its first MFMA)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) b[rt] = __builtin_bit_cast(bf16x8, *(const uint4*)(img_x + xbase[j] + rt * 4096));
+        __builtin_amdgcn_sched_barrier(0);  // (pinned like mm below: hipcc serialised the later k-steps read by read)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_x[j], b[rt], acc[0][rt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (s > 0) mm(std::integral_constant<int, 0>{}, img_h0, w_hh0);
     }
